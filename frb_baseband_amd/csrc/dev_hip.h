@@ -1,0 +1,71 @@
+// gfx950 device layer for frbch_engine.cpp: kernel macro layer, launches, memory, events.
+#ifndef FRBCH_DEV_HIP_H
+#define FRBCH_DEV_HIP_H
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+#define FRBCH_BACKEND_NAME "hip-gfx950"
+#define DEVFN __device__
+#define KERNEL(name, PT) extern "C" __global__ void __launch_bounds__(256) name(PT p)
+#define K_PROLOGUE                                                                  \
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];              \
+  const int bx = blockIdx.x, by = blockIdx.y, nthr = blockDim.x
+#define PHASE for (int tid = threadIdx.x, once_ = 1; once_; once_ = 0)
+#define SYNC __syncthreads()
+#define FMUL_RN(a, b) __fmul_rn((a), (b))
+#define FADD_RN(a, b) __fadd_rn((a), (b))
+
+typedef hipStream_t dev_stream_t;
+typedef hipEvent_t dev_event_t;
+
+#define DEV_LAUNCH(kern, gx, gy, nthr, lds, stream, params) \
+  hipLaunchKernelGGL(kern, dim3((unsigned)(gx), (unsigned)(gy)), dim3((unsigned)(nthr)), (lds), (stream), (params))
+
+static inline const char* dev_last_error_string() { return hipGetErrorString(hipGetLastError()); }
+static inline int dev_count() {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+static inline int dev_set(int d) { return hipSetDevice(d) == hipSuccess ? 0 : -1; }
+static inline int dev_arch_ok(int d, char* name, size_t cap, size_t* lds_limit) {
+  hipDeviceProp_t pr;
+  if (hipGetDeviceProperties(&pr, d) != hipSuccess) return 0;
+  snprintf(name, cap, "%s", pr.gcnArchName);
+  *lds_limit = pr.maxSharedMemoryPerMultiProcessor ? (size_t)pr.maxSharedMemoryPerMultiProcessor : 65536;
+  if (*lds_limit > 160 * 1024) *lds_limit = 160 * 1024;
+  return 1;
+}
+template <class K>
+static inline int dev_allow_lds(K kern, size_t bytes) {
+  return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : -1;
+}
+static inline int dev_malloc(void** p, size_t n) { return hipMalloc(p, n ? n : 1) == hipSuccess ? 0 : -1; }
+static inline void dev_free(void* p) { if (p) (void)hipFree(p); }
+static inline int dev_h2d(void* d, const void* h, size_t n, dev_stream_t s) {
+  return hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s) == hipSuccess ? 0 : -1;
+}
+static inline int dev_d2h(void* h, const void* d, size_t n, dev_stream_t s) {
+  return hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s) == hipSuccess ? 0 : -1;
+}
+static inline int dev_d2d(void* d, const void* s_, size_t n, dev_stream_t s) {
+  return hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s) == hipSuccess ? 0 : -1;
+}
+static inline int dev_memset(void* d, int v, size_t n, dev_stream_t s) {
+  return hipMemsetAsync(d, v, n, s) == hipSuccess ? 0 : -1;
+}
+static inline int dev_sync(dev_stream_t s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
+static inline int dev_stream_create(dev_stream_t* s) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking) == hipSuccess ? 0 : -1; }
+static inline void dev_stream_destroy(dev_stream_t s) { (void)hipStreamDestroy(s); }
+static inline int dev_check_launch() { return hipGetLastError() == hipSuccess ? 0 : -1; }
+static inline int dev_host_alloc(void** p, size_t n) { return hipHostMalloc(p, n, hipHostMallocDefault) == hipSuccess ? 0 : -1; }
+static inline void dev_host_free(void* p) { if (p) (void)hipHostFree(p); }
+static inline int dev_event_create(dev_event_t* e) { return hipEventCreate(e) == hipSuccess ? 0 : -1; }
+static inline void dev_event_destroy(dev_event_t e) { (void)hipEventDestroy(e); }
+static inline void dev_event_record(dev_event_t e, dev_stream_t s) { (void)hipEventRecord(e, s); }
+static inline float dev_event_ms(dev_event_t a, dev_event_t b) {
+  float ms = 0.f;
+  (void)hipEventSynchronize(b);
+  (void)hipEventElapsedTime(&ms, a, b);
+  return ms;
+}
+#endif

@@ -1,0 +1,717 @@
+// libfrbch compute side: handle life cycle, kernel sequencing, rescale-interval state machine,
+// host streaming (push/pull/run_file) and the device-resident entry points of include/frbch.h.
+//
+// Compiled as HIP for gfx950 (FRBCH_DEV_HEADER = "dev_hip.h").  The CPU unit tests compile the
+// same file against tests/emu/dev_emu.h to exercise the host logic without a GPU; that build is
+// test infrastructure and is never loaded by the package.
+#include FRBCH_DEV_HEADER
+
+#include <errno.h>
+#include <fcntl.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "frbch_host.h"
+#include "frbch_kparams.h"
+
+#include "kernels_generic.inc"
+
+using namespace frbch;
+
+namespace {
+
+enum { KID_K1 = 0, KID_KC, KID_K2, KID_STATS, KID_QUANT, KID_COUNT };
+const char* const kKernelNames[KID_COUNT] = {"frbch_k1_branch", "frbch_kc_dcfix", "frbch_k2_chan",
+                                             "frbch_stats", "frbch_quantise"};
+
+struct EventPair {
+  dev_event_t a, b;
+  int kid;
+  double bytes;
+};
+
+}  // namespace
+
+struct frbch_handle {
+  frbch_config cfg;
+  Plan pl;
+  std::string err;
+  int device = 0;
+  dev_stream_t stream = 0;
+  size_t lds_limit = 65536;
+
+  // constant tables
+  cf *tw_r = nullptr, *tw_c2 = nullptr, *tw_nhi = nullptr, *tw_nlo = nullptr;
+  // per-launch work buffers
+  cf *spill = nullptr, *s_dc = nullptr, *p0 = nullptr;
+  // rescale state
+  float *offset = nullptr, *scale = nullptr;
+  bool have_scale = false;     // offset/scale are defined
+  bool scale_frozen = false;   // ... and stay as they are (set_rescale, -c after 1st interval, -I0)
+  float* powbuf = nullptr;     // float power of the interval being measured [row][ncol]
+  uint64_t pow_cap_rows = 0, pow_rows = 0;
+  double* partial = nullptr;
+  int partial_chunks = 0;
+
+  uint64_t rows_out = 0, blocks_done = 0;
+
+  // VDIF stream state (host streaming path)
+  bool have_vdif = false;
+  VdifInfo v0{};
+  double tstart_mjd = 0.0;
+  uint64_t skip_bytes = 0;      // payload bytes still to skip before the next block starts
+  uint64_t blocks_budget = 0;   // blocks still allowed by -T
+  std::vector<uint8_t> carry;   // whole + partial frames not yet consumed
+  uint8_t* d_frames = nullptr;
+  size_t d_frames_cap = 0;
+  uint8_t* d_out = nullptr;
+  size_t d_out_cap = 0;
+  std::vector<uint8_t> outq;
+  size_t outq_pos = 0;
+
+  // profiling
+  bool profiling = false;
+  std::vector<EventPair> events;
+  double acc_ms[KID_COUNT] = {0};
+  double acc_bytes[KID_COUNT] = {0};
+  uint64_t acc_launches[KID_COUNT] = {0};
+};
+
+namespace {
+
+int fail(frbch_handle* h, int code, const std::string& msg) {
+  h->err = msg;
+  return code;
+}
+
+#define CHECK_DEV(h, expr, what)                                                           \
+  do {                                                                                     \
+    if ((expr) != 0) return fail((h), FRBCH_E_DEVICE, std::string(what) + ": " + dev_last_error_string()); \
+  } while (0)
+
+struct ProfScope {
+  frbch_handle* h;
+  dev_stream_t s;
+  EventPair ep;
+  bool on;
+  ProfScope(frbch_handle* h_, dev_stream_t s_, int kid, double bytes) : h(h_), s(s_), on(h_->profiling) {
+    if (on) {
+      ep.kid = kid;
+      ep.bytes = bytes;
+      dev_event_create(&ep.a);
+      dev_event_create(&ep.b);
+      dev_event_record(ep.a, s);
+    }
+  }
+  ~ProfScope() {
+    if (on) {
+      dev_event_record(ep.b, s);
+      h->events.push_back(ep);
+    }
+  }
+};
+
+void drain_events(frbch_handle* h) {
+  for (auto& e : h->events) {
+    h->acc_ms[e.kid] += dev_event_ms(e.a, e.b);
+    h->acc_bytes[e.kid] += e.bytes;
+    h->acc_launches[e.kid] += 1;
+    dev_event_destroy(e.a);
+    dev_event_destroy(e.b);
+  }
+  h->events.clear();
+}
+
+int upload_table(frbch_handle* h, cf** dst, uint64_t n, uint64_t count, uint64_t step) {
+  std::vector<float> tmp(2 * count);
+  fill_twiddles(tmp.data(), n, count, step);
+  CHECK_DEV(h, dev_malloc((void**)dst, count * sizeof(cf)), "hipMalloc(twiddles)");
+  CHECK_DEV(h, dev_h2d(*dst, tmp.data(), count * sizeof(cf), h->stream), "upload twiddles");
+  CHECK_DEV(h, dev_sync(h->stream), "sync");
+  return FRBCH_OK;
+}
+
+KParams base_params(const frbch_handle* h) {
+  const Plan& pl = h->pl;
+  KParams p;
+  memset(&p, 0, sizeof p);
+  p.log2_c2 = pl.log2_c2;
+  p.log2_r = pl.log2_r;
+  p.c = pl.c;
+  p.c2 = pl.c2;
+  p.r = pl.r;
+  p.g = pl.g;
+  p.tt = pl.tt;
+  p.tscr = pl.tscr;
+  p.nif = pl.nif;
+  p.pol_mode = h->cfg.pol_mode;
+  p.nbit = h->cfg.nbit_out;
+  p.flip = pl.flip;
+  p.log2_nlo = pl.log2_nlo;
+  p.spill = h->spill;
+  p.s_dc = h->s_dc;
+  p.p0 = h->p0;
+  p.tw_r = h->tw_r;
+  p.tw_c2 = h->tw_c2;
+  p.tw_nhi = h->tw_nhi;
+  p.tw_nlo = h->tw_nlo;
+  p.offset = h->offset;
+  p.scale = h->scale;
+  p.lut[0] = -3.3359f;
+  p.lut[1] = -1.0f;
+  p.lut[2] = 1.0f;
+  p.lut[3] = 3.3359f;
+  p.digi_mean = pl.digi_mean;
+  p.digi_scale = pl.digi_scale;
+  p.digi_max = pl.digi_max;
+  return p;
+}
+
+// K1 + Kc over nb blocks: frames -> spill, P0
+int launch_front(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
+  const Plan& pl = h->pl;
+  {
+    const double bytes = (double)nb * ((double)pl.block_payload_bytes * p.frame_bytes / p.payload_bytes +
+                                       (double)pl.n * 8.0 + (double)pl.c2 * 8.0);
+    ProfScope ps(h, s, KID_K1, bytes);
+    DEV_LAUNCH(frbch_k1_branch, pl.c2 / pl.g, nb, pl.nthreads, pl.k1_lds, s, p);
+  }
+  {
+    ProfScope ps(h, s, KID_KC, (double)nb * pl.c2 * 16.0);
+    DEV_LAUNCH(frbch_kc_dcfix, 1, nb, pl.nthreads, pl.kc_lds, s, p);
+  }
+  CHECK_DEV(h, dev_check_launch(), "launch K1/Kc");
+  return FRBCH_OK;
+}
+
+int launch_back(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
+  const Plan& pl = h->pl;
+  const int tile_t = std::max(pl.tt, pl.tscr);
+  const double out_b = p.out_mode == FRBCH_OUT_FLOAT_POWER ? (double)pl.ncol * 4.0 : (double)pl.row_bytes;
+  const double bytes = (double)nb * ((double)pl.n * 8.0 + (double)pl.rows_per_block * out_b);
+  ProfScope ps(h, s, KID_K2, bytes);
+  DEV_LAUNCH(frbch_k2_chan, pl.r / tile_t, nb, pl.nthreads, pl.k2_lds, s, p);
+  CHECK_DEV(h, dev_check_launch(), "launch K2");
+  return FRBCH_OK;
+}
+
+int ensure_powbuf(frbch_handle* h) {
+  if (h->powbuf) return FRBCH_OK;
+  const Plan& pl = h->pl;
+  h->pow_cap_rows = pl.interval_rows + (uint64_t)pl.maxb * pl.rows_per_block;
+  CHECK_DEV(h, dev_malloc((void**)&h->powbuf, h->pow_cap_rows * pl.ncol * sizeof(float)), "hipMalloc(power buffer)");
+  h->partial_chunks = 256;
+  CHECK_DEV(h, dev_malloc((void**)&h->partial, (size_t)h->partial_chunks * pl.ncol * 2 * sizeof(double)), "hipMalloc(partials)");
+  return FRBCH_OK;
+}
+
+int run_stats(frbch_handle* h, uint64_t rows, dev_stream_t s) {
+  const Plan& pl = h->pl;
+  StatParams sp;
+  memset(&sp, 0, sizeof sp);
+  sp.power = h->powbuf;
+  sp.partial = h->partial;
+  sp.rows = rows;
+  sp.ncol = (int)pl.ncol;
+  sp.c = pl.c;
+  sp.nif = pl.nif;
+  sp.flip = pl.flip;
+  sp.nchunk = (int)std::min<uint64_t>((uint64_t)h->partial_chunks, std::max<uint64_t>(1, rows / 64));
+  sp.rows_per_chunk = (rows + sp.nchunk - 1) / sp.nchunk;
+  sp.nchunk = (int)((rows + sp.rows_per_chunk - 1) / sp.rows_per_chunk);
+  sp.offset = h->offset;
+  sp.scale = h->scale;
+  const int gx = (int)((pl.ncol + 255) / 256);
+  ProfScope ps(h, s, KID_STATS, (double)rows * pl.ncol * 4.0);
+  DEV_LAUNCH(frbch_stats_partial, gx, sp.nchunk, 256, 0, s, sp);
+  DEV_LAUNCH(frbch_stats_final, gx, 1, 256, 0, s, sp);
+  CHECK_DEV(h, dev_check_launch(), "launch stats");
+  return FRBCH_OK;
+}
+
+int run_quantise(frbch_handle* h, uint64_t rows, uint8_t* dst, dev_stream_t s) {
+  const Plan& pl = h->pl;
+  QuantParams qp;
+  memset(&qp, 0, sizeof qp);
+  qp.power = h->powbuf;
+  qp.out = dst;
+  qp.rows = rows;
+  qp.ncol = (int)pl.ncol;
+  qp.c = pl.c;
+  qp.nif = pl.nif;
+  qp.flip = pl.flip;
+  qp.nbit = h->cfg.nbit_out;
+  qp.offset = h->offset;
+  qp.scale = h->scale;
+  qp.digi_mean = pl.digi_mean;
+  qp.digi_scale = pl.digi_scale;
+  qp.digi_max = pl.digi_max;
+  const int per = qp.nbit == 2 ? 4 : 1;
+  const uint64_t total = rows * pl.ncol / per;
+  const uint64_t gx = (total + 255) / 256;
+  if (gx > 0x7fffffffull) return fail(h, FRBCH_E_ARG, "rescale interval too large for one quantise launch");
+  ProfScope ps(h, s, KID_QUANT, (double)rows * (pl.ncol * 4.0 + pl.row_bytes));
+  DEV_LAUNCH(frbch_quantise, gx, 1, 256, 0, s, qp);
+  CHECK_DEV(h, dev_check_launch(), "launch quantise");
+  return FRBCH_OK;
+}
+
+// Close the rescale interval that sits at the front of powbuf: statistics over `stat_rows` rows,
+// then digitise `emit_rows` rows into dst and keep the rest for the next interval.
+int finalize_interval(frbch_handle* h, uint64_t stat_rows, uint8_t* d_out, size_t cap, uint64_t* rows_written,
+                      dev_stream_t s) {
+  const Plan& pl = h->pl;
+  int rc = run_stats(h, stat_rows, s);
+  if (rc) return rc;
+  h->have_scale = true;
+  if (h->cfg.rescale_constant) h->scale_frozen = true;
+  const uint64_t emit_rows = h->scale_frozen ? h->pow_rows : stat_rows;
+  if ((*rows_written + emit_rows) * pl.row_bytes > cap)
+    return fail(h, FRBCH_E_CAPACITY, "output buffer too small for the rows of a completed rescale interval");
+  rc = run_quantise(h, emit_rows, d_out + *rows_written * pl.row_bytes, s);
+  if (rc) return rc;
+  *rows_written += emit_rows;
+  h->rows_out += emit_rows;
+  const uint64_t rest = h->pow_rows - emit_rows;
+  // forward chunked move (chunks no longer than the shift distance never overlap)
+  uint64_t done = 0;
+  while (done < rest) {
+    const uint64_t len = std::min<uint64_t>(emit_rows, rest - done);
+    CHECK_DEV(h, dev_d2d(h->powbuf + done * pl.ncol, h->powbuf + (emit_rows + done) * pl.ncol,
+                         len * pl.ncol * sizeof(float), s), "move power rows");
+    done += len;
+  }
+  h->pow_rows = rest;
+  return FRBCH_OK;
+}
+
+bool fused_ok(const frbch_handle* h) { return h->scale_frozen; }
+
+// Transform `nblocks` blocks starting `payload_off` bytes into the payload stream of d_frames.
+int engine_feed(frbch_handle* h, const uint8_t* d_frames, uint32_t frame_bytes, uint32_t header_bytes,
+                uint64_t payload_off, uint64_t nblocks, uint8_t* d_out, size_t cap, uint64_t* rows_written,
+                dev_stream_t s) {
+  const Plan& pl = h->pl;
+  *rows_written = 0;
+  for (uint64_t b0 = 0; b0 < nblocks; b0 += pl.maxb) {
+    const uint32_t nb = (uint32_t)std::min<uint64_t>(pl.maxb, nblocks - b0);
+    KParams p = base_params(h);
+    p.frames = d_frames;
+    p.frame_bytes = frame_bytes;
+    p.header_bytes = header_bytes;
+    p.payload_bytes = frame_bytes - header_bytes;
+    p.payload_off = payload_off + b0 * pl.block_payload_bytes;
+    int rc = launch_front(h, p, nb, s);
+    if (rc) return rc;
+    const uint64_t rows = (uint64_t)nb * pl.rows_per_block;
+    if (fused_ok(h)) {
+      if ((*rows_written + rows) * pl.row_bytes > cap)
+        return fail(h, FRBCH_E_CAPACITY, "output buffer too small");
+      p.out_mode = FRBCH_OUT_CODES;
+      p.code_out = d_out;
+      p.row0 = *rows_written;
+      rc = launch_back(h, p, nb, s);
+      if (rc) return rc;
+      *rows_written += rows;
+      h->rows_out += rows;
+    } else {
+      rc = ensure_powbuf(h);
+      if (rc) return rc;
+      if (h->pow_rows + rows > h->pow_cap_rows) return fail(h, FRBCH_E_STATE, "power buffer overflow");
+      p.out_mode = FRBCH_OUT_FLOAT_POWER;
+      p.power_out = h->powbuf;
+      p.row0 = h->pow_rows;
+      rc = launch_back(h, p, nb, s);
+      if (rc) return rc;
+      h->pow_rows += rows;
+      while (!fused_ok(h) && h->pow_rows >= pl.interval_rows) {
+        rc = finalize_interval(h, pl.interval_rows, d_out, cap, rows_written, s);
+        if (rc) return rc;
+      }
+    }
+    h->blocks_done += nb;
+  }
+  return FRBCH_OK;
+}
+
+int engine_flush(frbch_handle* h, uint8_t* d_out, size_t cap, uint64_t* rows_written, dev_stream_t s) {
+  *rows_written = 0;
+  if (fused_ok(h) || h->pow_rows == 0) return FRBCH_OK;
+  return finalize_interval(h, std::min<uint64_t>(h->pow_rows, h->pl.interval_rows), d_out, cap, rows_written, s);
+}
+
+int set_identity_rescale(frbch_handle* h) {
+  const Plan& pl = h->pl;
+  std::vector<float> zero(pl.ncol, 0.0f), one(pl.ncol, 1.0f);
+  CHECK_DEV(h, dev_h2d(h->offset, zero.data(), pl.ncol * sizeof(float), h->stream), "upload offset");
+  CHECK_DEV(h, dev_h2d(h->scale, one.data(), pl.ncol * sizeof(float), h->stream), "upload scale");
+  CHECK_DEV(h, dev_sync(h->stream), "sync");
+  return FRBCH_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" const char* frbch_version(void) { return "frbch abi 1 backend " FRBCH_BACKEND_NAME; }
+
+extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
+  if (!cfg || !out) return FRBCH_E_ARG;
+  *out = nullptr;
+  if (cfg->size != sizeof(frbch_config) || cfg->abi_version != FRBCH_ABI_VERSION) return FRBCH_E_ARG;
+  frbch_handle* h = new frbch_handle();
+  h->cfg = *cfg;
+  *out = h;  // returned even on failure so that frbch_last_error works; caller closes it
+  if (cfg->device < 0) return fail(h, FRBCH_E_DEVICE, "device < 0: there is no CPU fallback");
+  const int ndev = dev_count();
+  if (ndev <= 0) return fail(h, FRBCH_E_DEVICE, "no GPU visible to HIP (there is no CPU fallback)");
+  if (cfg->device >= ndev) return fail(h, FRBCH_E_DEVICE, "device ordinal out of range");
+  h->device = cfg->device;
+  CHECK_DEV(h, dev_set(h->device), "hipSetDevice");
+  char arch[128] = "";
+  if (!dev_arch_ok(h->device, arch, sizeof arch, &h->lds_limit)) return fail(h, FRBCH_E_DEVICE, "cannot query device");
+  const std::string why = make_plan(h->cfg, &h->pl, h->lds_limit);
+  if (!why.empty()) return fail(h, FRBCH_E_ARG, why);
+  const Plan& pl = h->pl;
+  CHECK_DEV(h, dev_stream_create(&h->stream), "hipStreamCreate");
+  CHECK_DEV(h, dev_allow_lds(frbch_k1_branch, pl.k1_lds), "LDS size K1");
+  CHECK_DEV(h, dev_allow_lds(frbch_k2_chan, pl.k2_lds), "LDS size K2");
+  CHECK_DEV(h, dev_allow_lds(frbch_kc_dcfix, pl.kc_lds), "LDS size Kc");
+
+  int rc;
+  if ((rc = upload_table(h, &h->tw_r, pl.r, std::max(1, pl.r / 2), 1))) return rc;
+  if ((rc = upload_table(h, &h->tw_c2, pl.c2, pl.c, 1))) return rc;
+  const uint64_t nlo = 1ull << pl.log2_nlo, nhi = pl.n >> pl.log2_nlo;
+  if ((rc = upload_table(h, &h->tw_nlo, pl.n, nlo, 1))) return rc;
+  if ((rc = upload_table(h, &h->tw_nhi, pl.n, std::max<uint64_t>(1, nhi), nlo))) return rc;
+
+  CHECK_DEV(h, dev_malloc((void**)&h->spill, (size_t)pl.maxb * pl.n * sizeof(cf)), "hipMalloc(spill)");
+  CHECK_DEV(h, dev_malloc((void**)&h->s_dc, (size_t)pl.maxb * pl.c2 * sizeof(cf)), "hipMalloc(s_dc)");
+  CHECK_DEV(h, dev_malloc((void**)&h->p0, (size_t)pl.maxb * pl.c2 * sizeof(cf)), "hipMalloc(p0)");
+  CHECK_DEV(h, dev_malloc((void**)&h->offset, pl.ncol * sizeof(float)), "hipMalloc(offset)");
+  CHECK_DEV(h, dev_malloc((void**)&h->scale, pl.ncol * sizeof(float)), "hipMalloc(scale)");
+  if ((rc = set_identity_rescale(h))) return rc;
+  if (pl.interval_rows == 0) {  // -I0: no rescale, digitise the raw power
+    h->have_scale = true;
+    h->scale_frozen = true;
+  }
+  return FRBCH_OK;
+}
+
+extern "C" void frbch_close(frbch_handle* h) {
+  if (!h) return;
+  if (h->stream) (void)dev_sync(h->stream);
+  drain_events(h);
+  dev_free(h->tw_r); dev_free(h->tw_c2); dev_free(h->tw_nhi); dev_free(h->tw_nlo);
+  dev_free(h->spill); dev_free(h->s_dc); dev_free(h->p0);
+  dev_free(h->offset); dev_free(h->scale); dev_free(h->powbuf); dev_free(h->partial);
+  dev_free(h->d_frames); dev_free(h->d_out);
+  if (h->stream) dev_stream_destroy(h->stream);
+  delete h;
+}
+
+extern "C" const char* frbch_last_error(frbch_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+extern "C" int frbch_get_info(frbch_handle* h, frbch_info* info) {
+  if (!h || !info) return FRBCH_E_ARG;
+  const Plan& pl = h->pl;
+  memset(info, 0, sizeof *info);
+  info->size = (uint32_t)sizeof *info;
+  info->nchan = pl.c; info->freq_res = pl.r; info->tscrunch = pl.tscr; info->nif = pl.nif;
+  info->block_samples = pl.n;
+  info->block_payload_bytes = pl.block_payload_bytes;
+  info->rows_per_block = pl.rows_per_block;
+  info->row_bytes = pl.row_bytes;
+  info->rescale_interval_rows = pl.interval_rows;
+  info->rows_out = h->rows_out;
+  info->blocks_done = h->blocks_done;
+  info->tsamp_s = pl.tsamp_s;
+  info->tstart_mjd = h->tstart_mjd;
+  info->fch1_mhz = pl.fch1; info->foff_mhz = pl.foff;
+  info->frame_bytes = h->have_vdif ? h->v0.frame_bytes : 0;
+  info->header_bytes = h->have_vdif ? h->v0.header_bytes() : 0;
+  info->have_rescale = h->have_scale ? 1 : 0;
+  return FRBCH_OK;
+}
+
+extern "C" int frbch_get_rescale(frbch_handle* h, float* offset, float* scale) {
+  if (!h || !offset || !scale) return FRBCH_E_ARG;
+  if (!h->have_scale) return fail(h, FRBCH_E_STATE, "rescale not measured yet");
+  CHECK_DEV(h, dev_d2h(offset, h->offset, h->pl.ncol * sizeof(float), h->stream), "download offset");
+  CHECK_DEV(h, dev_d2h(scale, h->scale, h->pl.ncol * sizeof(float), h->stream), "download scale");
+  CHECK_DEV(h, dev_sync(h->stream), "sync");
+  return FRBCH_OK;
+}
+
+extern "C" int frbch_set_rescale(frbch_handle* h, const float* offset, const float* scale) {
+  if (!h || !offset || !scale) return FRBCH_E_ARG;
+  if (h->pow_rows) return fail(h, FRBCH_E_STATE, "set_rescale while an interval is being measured");
+  CHECK_DEV(h, dev_h2d(h->offset, offset, h->pl.ncol * sizeof(float), h->stream), "upload offset");
+  CHECK_DEV(h, dev_h2d(h->scale, scale, h->pl.ncol * sizeof(float), h->stream), "upload scale");
+  CHECK_DEV(h, dev_sync(h->stream), "sync");
+  h->have_scale = true;
+  h->scale_frozen = true;
+  return FRBCH_OK;
+}
+
+extern "C" int frbch_process_device(frbch_handle* h, const void* d_frames, size_t nframes, uint32_t frame_bytes,
+                                    uint32_t header_bytes, uint64_t payload_byte_offset, uint64_t nblocks,
+                                    void* d_out, size_t out_cap_bytes, uint64_t* rows_written, void* stream) {
+  if (!h || !d_frames || !rows_written || frame_bytes <= header_bytes) return FRBCH_E_ARG;
+  const uint64_t payload = (uint64_t)nframes * (frame_bytes - header_bytes);
+  if (payload_byte_offset + nblocks * h->pl.block_payload_bytes > payload)
+    return fail(h, FRBCH_E_ARG, "frames do not cover the requested blocks");
+  if (nblocks && !d_out) return FRBCH_E_ARG;
+  dev_stream_t s = stream ? (dev_stream_t)stream : h->stream;
+  return engine_feed(h, (const uint8_t*)d_frames, frame_bytes, header_bytes, payload_byte_offset, nblocks,
+                     (uint8_t*)d_out, out_cap_bytes, rows_written, s);
+}
+
+extern "C" int frbch_flush_device(frbch_handle* h, void* d_out, size_t out_cap_bytes, uint64_t* rows_written,
+                                  void* stream) {
+  if (!h || !rows_written) return FRBCH_E_ARG;
+  dev_stream_t s = stream ? (dev_stream_t)stream : h->stream;
+  return engine_flush(h, (uint8_t*)d_out, out_cap_bytes, rows_written, s);
+}
+
+extern "C" int frbch_power_device(frbch_handle* h, const void* d_frames, size_t nframes, uint32_t frame_bytes,
+                                  uint32_t header_bytes, uint64_t payload_byte_offset, uint64_t nblocks,
+                                  float* d_power, size_t cap_bytes, void* stream) {
+  if (!h || !d_frames || !d_power || frame_bytes <= header_bytes) return FRBCH_E_ARG;
+  const Plan& pl = h->pl;
+  const uint64_t payload = (uint64_t)nframes * (frame_bytes - header_bytes);
+  if (payload_byte_offset + nblocks * pl.block_payload_bytes > payload)
+    return fail(h, FRBCH_E_ARG, "frames do not cover the requested blocks");
+  if (nblocks * pl.rows_per_block * pl.ncol * sizeof(float) > cap_bytes)
+    return fail(h, FRBCH_E_CAPACITY, "power buffer too small");
+  dev_stream_t s = stream ? (dev_stream_t)stream : h->stream;
+  for (uint64_t b0 = 0; b0 < nblocks; b0 += pl.maxb) {
+    const uint32_t nb = (uint32_t)std::min<uint64_t>(pl.maxb, nblocks - b0);
+    KParams p = base_params(h);
+    p.frames = (const uint8_t*)d_frames;
+    p.frame_bytes = frame_bytes;
+    p.header_bytes = header_bytes;
+    p.payload_bytes = frame_bytes - header_bytes;
+    p.payload_off = payload_byte_offset + b0 * pl.block_payload_bytes;
+    int rc = launch_front(h, p, nb, s);
+    if (rc) return rc;
+    p.out_mode = FRBCH_OUT_FLOAT_POWER;
+    p.power_out = d_power;
+    p.row0 = b0 * pl.rows_per_block;
+    rc = launch_back(h, p, nb, s);
+    if (rc) return rc;
+  }
+  return FRBCH_OK;
+}
+
+// ---- profiling ---------------------------------------------------------------------------------
+extern "C" int frbch_set_profiling(frbch_handle* h, int enable) {
+  if (!h) return FRBCH_E_ARG;
+  h->profiling = enable != 0;
+  return FRBCH_OK;
+}
+extern "C" int frbch_timing_reset(frbch_handle* h) {
+  if (!h) return FRBCH_E_ARG;
+  (void)dev_sync(h->stream);
+  drain_events(h);
+  for (int i = 0; i < KID_COUNT; ++i) h->acc_ms[i] = h->acc_bytes[i] = 0.0, h->acc_launches[i] = 0;
+  return FRBCH_OK;
+}
+extern "C" int frbch_get_timing(frbch_handle* h, frbch_timing* t) {
+  if (!h || !t) return FRBCH_E_ARG;
+  drain_events(h);
+  memset(t, 0, sizeof *t);
+  t->size = (uint32_t)sizeof *t;
+  t->nkernels = KID_COUNT;
+  for (int i = 0; i < KID_COUNT; ++i) {
+    snprintf(t->k[i].name, sizeof t->k[i].name, "%s", kKernelNames[i]);
+    t->k[i].launches = h->acc_launches[i];
+    t->k[i].total_ms = h->acc_ms[i];
+    t->k[i].algorithmic_bytes = h->acc_bytes[i];
+  }
+  return FRBCH_OK;
+}
+
+// ---- host streaming -----------------------------------------------------------------------------
+namespace {
+
+int stream_begin(frbch_handle* h, const uint8_t* first_frame) {
+  VdifInfo v;
+  if (!parse_vdif_header(first_frame, &v)) return fail(h, FRBCH_E_FORMAT, "not a VDIF frame header");
+  std::string why;
+  if (!check_vdif_supported(v, &why)) return fail(h, FRBCH_E_FORMAT, "unsupported VDIF stream: " + why);
+  h->v0 = v;
+  h->have_vdif = true;
+  const Plan& pl = h->pl;
+  const double fps = pl.rate_in * 2.0 * 2.0 / 8.0 / v.payload_bytes();
+  uint64_t s0 = (uint64_t)llround(h->cfg.start_s * pl.rate_in);
+  s0 -= s0 % 2;
+  h->skip_bytes = s0 / 2;
+  const double want = h->cfg.total_s * pl.rate_in;
+  h->blocks_budget = want >= 9.0e18 ? UINT64_MAX : (uint64_t)llround(want) / pl.n;
+  h->tstart_mjd = (double)vdif_epoch_mjd((int)v.ref_epoch) +
+                  ((double)v.seconds + (double)v.frame_nr / fps + (double)s0 / pl.rate_in) / 86400.0;
+  // device staging: frames of one launch batch, output of one batch (+ a completed interval)
+  const uint64_t pb = v.payload_bytes();
+  const uint64_t nfr = ((uint64_t)pl.maxb * pl.block_payload_bytes + pb - 1) / pb + 2;
+  h->d_frames_cap = nfr * v.frame_bytes;
+  CHECK_DEV(h, dev_malloc((void**)&h->d_frames, h->d_frames_cap), "hipMalloc(frame staging)");
+  const uint64_t burst_rows = pl.interval_rows + 2ull * pl.maxb * pl.rows_per_block;
+  h->d_out_cap = burst_rows * pl.row_bytes;
+  CHECK_DEV(h, dev_malloc((void**)&h->d_out, h->d_out_cap), "hipMalloc(output staging)");
+  return FRBCH_OK;
+}
+
+int queue_rows(frbch_handle* h, uint64_t rows) {
+  if (!rows) return FRBCH_OK;
+  const size_t nbytes = rows * h->pl.row_bytes;
+  if (h->outq_pos && h->outq_pos == h->outq.size()) {
+    h->outq.clear();
+    h->outq_pos = 0;
+  }
+  const size_t old = h->outq.size();
+  h->outq.resize(old + nbytes);
+  CHECK_DEV(h, dev_d2h(h->outq.data() + old, h->d_out, nbytes, h->stream), "download rows");
+  CHECK_DEV(h, dev_sync(h->stream), "sync");
+  return FRBCH_OK;
+}
+
+int process_carry(frbch_handle* h) {
+  const Plan& pl = h->pl;
+  const uint64_t fb = h->v0.frame_bytes, hb = h->v0.header_bytes(), pb = h->v0.payload_bytes();
+  size_t consumed_frames = 0;  // frames at the front of carry that are fully used
+  for (;;) {
+    // drop frames that -S skips entirely
+    const uint64_t frames_avail = (h->carry.size() - consumed_frames * fb) / fb;
+    const uint64_t drop = std::min<uint64_t>(h->skip_bytes / pb, frames_avail);
+    consumed_frames += drop;
+    h->skip_bytes -= drop * pb;
+    const uint64_t fa = frames_avail - drop;
+    if (fa * pb < h->skip_bytes + pl.block_payload_bytes || h->blocks_budget == 0) break;
+    uint64_t nb = (fa * pb - h->skip_bytes) / pl.block_payload_bytes;
+    nb = std::min<uint64_t>(nb, std::min<uint64_t>(pl.maxb, h->blocks_budget));
+    const uint64_t need_frames = (h->skip_bytes + nb * pl.block_payload_bytes + pb - 1) / pb;
+    const uint8_t* src = h->carry.data() + consumed_frames * fb;
+    CHECK_DEV(h, dev_h2d(h->d_frames, src, need_frames * fb, h->stream), "upload frames");
+    uint64_t rows = 0;
+    int rc = engine_feed(h, h->d_frames, (uint32_t)fb, (uint32_t)hb, h->skip_bytes, nb, h->d_out, h->d_out_cap,
+                         &rows, h->stream);
+    if (rc) return rc;
+    rc = queue_rows(h, rows);  // also synchronises, so `src` may be released
+    if (rc) return rc;
+    if (!rows) CHECK_DEV(h, dev_sync(h->stream), "sync");
+    h->blocks_budget -= nb;
+    h->skip_bytes += nb * pl.block_payload_bytes;
+  }
+  if (consumed_frames) h->carry.erase(h->carry.begin(), h->carry.begin() + consumed_frames * fb);
+  if (h->blocks_budget == 0) h->carry.clear();  // -T reached: ignore the rest
+  return FRBCH_OK;
+}
+
+}  // namespace
+
+extern "C" int frbch_push(frbch_handle* h, const uint8_t* frames, size_t nbytes) {
+  if (!h || (!frames && nbytes)) return FRBCH_E_ARG;
+  if (h->have_vdif && h->blocks_budget == 0) return FRBCH_OK;
+  h->carry.insert(h->carry.end(), frames, frames + nbytes);
+  if (!h->have_vdif) {
+    if (h->carry.size() < 32) return FRBCH_OK;
+    const int rc = stream_begin(h, h->carry.data());
+    if (rc) return rc;
+  }
+  return process_carry(h);
+}
+
+extern "C" int frbch_flush(frbch_handle* h) {
+  if (!h) return FRBCH_E_ARG;
+  if (!h->have_vdif) return FRBCH_OK;
+  uint64_t rows = 0;
+  int rc = engine_flush(h, h->d_out, h->d_out_cap, &rows, h->stream);
+  if (rc) return rc;
+  return queue_rows(h, rows);
+}
+
+extern "C" long frbch_pull(frbch_handle* h, uint8_t* dst, size_t cap) {
+  if (!h || (!dst && cap)) return FRBCH_E_ARG;
+  const size_t avail = h->outq.size() - h->outq_pos;
+  const size_t n = std::min(avail, cap);
+  if (n) memcpy(dst, h->outq.data() + h->outq_pos, n);
+  h->outq_pos += n;
+  return (long)n;
+}
+
+extern "C" long frbch_sigproc_header(frbch_handle* h, uint8_t* dst, size_t cap) {
+  if (!h) return FRBCH_E_ARG;
+  if (!h->have_vdif) return fail(h, FRBCH_E_STATE, "no VDIF frame seen yet");
+  const std::vector<uint8_t> hdr = sigproc_header(h->cfg, h->pl, h->tstart_mjd);
+  if (hdr.size() > cap) return fail(h, FRBCH_E_CAPACITY, "header buffer too small");
+  memcpy(dst, hdr.data(), hdr.size());
+  return (long)hdr.size();
+}
+
+namespace {
+bool write_all(int fd, const uint8_t* p, size_t n) {
+  while (n) {
+    const ssize_t w = write(fd, p, n);
+    if (w < 0) {
+      if (errno == EINTR) continue;
+      return false;
+    }
+    p += w;
+    n -= (size_t)w;
+  }
+  return true;
+}
+}  // namespace
+
+extern "C" int frbch_run_file(frbch_handle* h, const char* vdif_path, const char* out_fil) {
+  if (!h || !vdif_path || !out_fil) return FRBCH_E_ARG;
+  FILE* in = fopen(vdif_path, "rb");
+  if (!in) return fail(h, FRBCH_E_IO, std::string("cannot open ") + vdif_path + ": " + strerror(errno));
+  // INSTALL.md:32-35: no O_EXCL, so that a pre-made FIFO (base2fil.sh:348-349) can be the target
+  const int fd = open(out_fil, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  if (fd < 0) {
+    fclose(in);
+    return fail(h, FRBCH_E_IO, std::string("cannot open ") + out_fil + ": " + strerror(errno));
+  }
+  int rc = FRBCH_OK;
+  std::vector<uint8_t> buf(32u << 20), out(8u << 20);
+  bool header_done = false;
+  auto drain = [&]() -> int {
+    if (!header_done && h->have_vdif) {
+      const long n = frbch_sigproc_header(h, out.data(), out.size());
+      if (n < 0) return (int)n;
+      if (!write_all(fd, out.data(), (size_t)n)) return fail(h, FRBCH_E_IO, std::string("write: ") + strerror(errno));
+      header_done = true;
+    }
+    for (;;) {
+      const long n = frbch_pull(h, out.data(), out.size());
+      if (n < 0) return (int)n;
+      if (n == 0) return FRBCH_OK;
+      if (!write_all(fd, out.data(), (size_t)n)) return fail(h, FRBCH_E_IO, std::string("write: ") + strerror(errno));
+    }
+  };
+  // -S: skip whole frames by seeking (the engine skips the remainder inside the first frame)
+  for (;;) {
+    const size_t n = fread(buf.data(), 1, buf.size(), in);
+    if (n == 0) break;
+    if ((rc = frbch_push(h, buf.data(), n))) break;
+    if ((rc = drain())) break;
+    if (h->have_vdif && h->blocks_budget == 0) break;
+  }
+  if (!rc) rc = frbch_flush(h);
+  if (!rc) rc = drain();
+  if (!rc && !header_done) rc = fail(h, FRBCH_E_FORMAT, "input holds no complete VDIF frame");
+  fclose(in);
+  if (close(fd) != 0 && !rc) rc = fail(h, FRBCH_E_IO, std::string("close: ") + strerror(errno));
+  return rc;
+}

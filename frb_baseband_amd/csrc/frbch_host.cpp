@@ -1,0 +1,406 @@
+// Host-side (no GPU) pieces of libfrbch: .hdr / digifil-argv / VDIF / SIGPROC handling and the
+// geometry plan.  Reference anchors are cited per function.
+#include "frbch_host.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <fstream>
+#include <sstream>
+
+namespace frbch {
+
+// ---------------------------------------------------------------------------------------------
+// VDIF
+// ---------------------------------------------------------------------------------------------
+static uint32_t rd32(const uint8_t* p) {
+  return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+bool parse_vdif_header(const uint8_t* buf, VdifInfo* v) {
+  const uint32_t w0 = rd32(buf), w1 = rd32(buf + 4), w2 = rd32(buf + 8), w3 = rd32(buf + 12);
+  v->invalid = (w0 >> 31) & 1;
+  v->legacy = (w0 >> 30) & 1;
+  v->seconds = w0 & 0x3FFFFFFFu;
+  v->ref_epoch = (w1 >> 24) & 0x3F;
+  v->frame_nr = w1 & 0xFFFFFFu;
+  v->log2_nchan = (w2 >> 24) & 0x1F;
+  v->frame_bytes = (w2 & 0xFFFFFFu) * 8u;
+  v->is_complex = (w3 >> 31) & 1;
+  v->bits_per_sample = ((w3 >> 26) & 0x1F) + 1;
+  v->thread_id = (w3 >> 16) & 0x3FF;
+  v->station_id = w3 & 0xFFFF;
+  return v->frame_bytes > v->header_bytes();
+}
+
+bool check_vdif_supported(const VdifInfo& v, std::string* why) {
+  std::ostringstream o;
+  if (v.bits_per_sample != 2) o << "bits/sample = " << v.bits_per_sample << " (need 2); ";
+  if (v.log2_nchan != 1) o << "channels = " << (1u << v.log2_nchan) << " (need 2 = two pols); ";
+  if (v.is_complex) o << "complex samples (need real); ";
+  if (v.payload_bytes() % 8) o << "payload not a multiple of 8 bytes; ";
+  *why = o.str();
+  return why->empty();
+}
+
+int vdif_epoch_mjd(int ref_epoch) {
+  const int year = 2000 + ref_epoch / 2;
+  const int month = (ref_epoch % 2 == 0) ? 1 : 7;
+  const int a = (14 - month) / 12;
+  const int y = year + 4800 - a;
+  const int m = month + 12 * a - 3;
+  const long jdn = 1 + (153 * m + 2) / 5 + 365L * y + y / 4 - y / 100 + y / 400 - 32045;
+  return (int)(jdn - 2400001);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Plan
+// ---------------------------------------------------------------------------------------------
+static int ilog2(uint64_t v) {
+  int l = 0;
+  while ((1ull << l) < v) ++l;
+  return l;
+}
+static bool is_pow2(uint64_t v) { return v && !(v & (v - 1)); }
+static int pow2_floor(uint64_t v) {
+  int p = 1;
+  while ((uint64_t)p * 2 <= v) p *= 2;
+  return p;
+}
+
+std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit) {
+  std::ostringstream e;
+  if (cfg.nchan < 2 || !is_pow2(cfg.nchan) || cfg.nchan > 8192)
+    return "nchan must be a power of two in [2, 8192]";
+  uint32_t r = cfg.freq_res ? cfg.freq_res : (cfg.nchan <= 128 ? 512u : 2u * cfg.nchan);
+  if (r < 2 || !is_pow2(r) || r > 16384) return "freq_res must be a power of two in [2, 16384]";
+  const uint32_t t = cfg.tscrunch ? cfg.tscrunch : 1;
+  if (!is_pow2(t) || t > r) return "tscrunch must be a power of two not larger than freq_res";
+  if (cfg.pol_mode < 0 || cfg.pol_mode > 4) {
+    e << "pol = " << cfg.pol_mode << " not implemented. Choices are 0, 1, 2, 3, 4";
+    return e.str();
+  }
+  if (cfg.nbit_out != 2 && cfg.nbit_out != 8 && cfg.nbit_out != 16 && cfg.nbit_out != -32) {
+    e << "nbit=" << cfg.nbit_out << " not in supported values of [2, 8, 16, -32]. ";
+    return e.str();
+  }
+  if (cfg.bw_mhz == 0.0 || !(fabs(cfg.bw_mhz) < 1.0e4)) return "BW must be non-zero";
+  if (cfg.coherent) return "coherent dedispersion (-F nchan:D) is not implemented";
+  if (cfg.start_s < 0 || cfg.total_s < 0) return "-S and -T must be non-negative";
+
+  pl->c = (int)cfg.nchan;
+  pl->r = (int)r;
+  pl->c2 = 2 * pl->c;
+  pl->log2_c2 = ilog2(pl->c2);
+  pl->log2_r = ilog2(r);
+  pl->n = (uint64_t)pl->c2 * r;
+  pl->log2_n = pl->log2_c2 + pl->log2_r;
+  pl->log2_nlo = (pl->log2_n + 1) / 2;
+  pl->tscr = (int)t;
+  pl->nif = cfg.pol_mode == 4 ? 4 : 1;
+  pl->flip = cfg.bw_mhz > 0 ? 1 : 0;
+  pl->nthreads = 256;
+  pl->ncol = (uint64_t)pl->nif * pl->c;
+  if (cfg.nbit_out == 2 && (pl->ncol % 4)) return "2-bit output needs nif*nchan divisible by 4";
+  pl->block_payload_bytes = pl->n / 2;
+  pl->rows_per_block = r / t;
+  const int nb = cfg.nbit_out < 0 ? 32 : cfg.nbit_out;
+  pl->row_bytes = pl->ncol * nb / 8;
+
+  // LDS tiling: prefer two resident workgroups per CU (80 KiB each), allow one big one.
+  const size_t pref = std::min<size_t>(lds_limit, 80 * 1024);
+  const size_t seq1 = (size_t)(r + 1) * 8;
+  size_t gmax = pref / seq1;
+  if (gmax < 1) gmax = 1;
+  pl->g = std::min<int>(pow2_floor(gmax), pl->c2);
+  pl->k1_lds = (size_t)pl->g * seq1;
+  if (pl->k1_lds > lds_limit) return "freq_res too large for the LDS of this device";
+
+  const size_t row1 = (size_t)(pl->c2 + 1) * 8;
+  size_t tmax = pref / row1;
+  if (tmax < 1) tmax = 1;
+  pl->tt = std::min<int>(pow2_floor(tmax), (int)r);
+  pl->k2_lds = (size_t)pl->tt * row1;
+  if (pl->tscr > pl->tt) pl->k2_lds += pl->ncol * 4;
+  if (pl->k2_lds > lds_limit) return "nchan (x tscrunch accumulators) too large for the LDS";
+  pl->kc_lds = (size_t)pl->c2 * 8;
+
+  pl->rate_in = 2.0e6 * fabs(cfg.bw_mhz);
+  pl->rate_out = fabs(cfg.bw_mhz) * 1.0e6 / ((double)pl->c * t);
+  pl->tsamp_s = (double)pl->c * t / (fabs(cfg.bw_mhz) * 1.0e6);  // create_config.py:561
+  pl->interval_rows = 0;
+  if (cfg.rescale_interval_s > 0) {
+    pl->interval_rows = (uint64_t)(cfg.rescale_interval_s * pl->rate_out);  // uint64 cast
+    if (pl->interval_rows < 1) pl->interval_rows = 1;
+  }
+  const double df = fabs(cfg.bw_mhz) / pl->c;
+  pl->fch1 = cfg.freq_mhz + fabs(cfg.bw_mhz) / 2.0 - df / 2.0;
+  pl->foff = -df;
+
+  switch (cfg.nbit_out) {
+    case 2: pl->digi_mean = 1.5f; pl->digi_scale = 1.0f; pl->digi_max = 3.0f; break;
+    case 8: pl->digi_mean = 127.5f; pl->digi_scale = (float)(127.5 / 6.0); pl->digi_max = 255.0f; break;
+    case 16: pl->digi_mean = 32767.5f; pl->digi_scale = (float)(32767.5 / 6.0); pl->digi_max = 65535.0f; break;
+    default: pl->digi_mean = 0.0f; pl->digi_scale = 1.0f; pl->digi_max = 0.0f; break;
+  }
+
+  uint32_t maxb = cfg.max_blocks_per_launch;
+  if (!maxb) {
+    const uint64_t spill_per_block = pl->n * 8;
+    maxb = (uint32_t)std::max<uint64_t>(1, (128ull << 20) / spill_per_block);
+    if (maxb > 256) maxb = 256;
+  }
+  if (maxb > 32768) maxb = 32768;
+  pl->maxb = maxb;
+  return "";
+}
+
+void fill_twiddles(float* dst, uint64_t n, uint64_t count, uint64_t step) {
+  for (uint64_t k = 0; k < count; ++k) {
+    const uint64_t q = (k * step) % n;
+    // reduce to the first octant-ish range through exact symmetries for accuracy
+    const double a = -2.0 * M_PI * (double)q / (double)n;
+    dst[2 * k] = (float)cos(a);
+    dst[2 * k + 1] = (float)sin(a);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SIGPROC header (public sigproc format; consumer is `splice`, base2fil.sh:422)
+// ---------------------------------------------------------------------------------------------
+static void put_str(std::vector<uint8_t>& v, const std::string& s) {
+  const int32_t n = (int32_t)s.size();
+  const uint8_t* p = (const uint8_t*)&n;
+  v.insert(v.end(), p, p + 4);
+  v.insert(v.end(), s.begin(), s.end());
+}
+static void put_i(std::vector<uint8_t>& v, const char* key, int32_t x) {
+  put_str(v, key);
+  const uint8_t* p = (const uint8_t*)&x;
+  v.insert(v.end(), p, p + 4);
+}
+static void put_d(std::vector<uint8_t>& v, const char* key, double x) {
+  put_str(v, key);
+  const uint8_t* p = (const uint8_t*)&x;
+  v.insert(v.end(), p, p + 8);
+}
+
+double sigproc_angle(const char* text) {
+  std::string t(text);
+  size_t b = t.find_first_not_of(" \t");
+  if (b == std::string::npos) return 0.0;
+  t = t.substr(b);
+  double sign = 1.0;
+  if (t[0] == '-') sign = -1.0;
+  while (!t.empty() && (t[0] == '-' || t[0] == '+')) t.erase(0, 1);
+  double part[3] = {0, 0, 0};
+  std::stringstream ss(t);
+  std::string item;
+  for (int i = 0; i < 3 && std::getline(ss, item, ':'); ++i) part[i] = atof(item.c_str());
+  return sign * (part[0] * 10000.0 + part[1] * 100.0 + part[2]);
+}
+
+int sigproc_telescope_id(const char* name) {
+  static const struct { const char* n; int id; } tab[] = {
+      {"fake", 0}, {"arecibo", 1}, {"ooty", 2}, {"nancay", 3}, {"parkes", 4}, {"jodrell", 5},
+      {"gbt", 6}, {"gmrt", 7}, {"effelsberg", 8}, {"ata", 9}, {"srt", 10}, {"lofar", 11},
+      {"vla", 12}};
+  std::string s(name);
+  std::transform(s.begin(), s.end(), s.begin(), ::tolower);
+  for (auto& t : tab)
+    if (s == t.n) return t.id;
+  return 0;
+}
+
+std::vector<uint8_t> sigproc_header(const frbch_config& cfg, const Plan& pl, double tstart_mjd) {
+  std::vector<uint8_t> v;
+  put_str(v, "HEADER_START");
+  put_i(v, "telescope_id", sigproc_telescope_id(cfg.telescope));
+  put_i(v, "machine_id", 0);
+  put_i(v, "data_type", 1);
+  std::string raw(cfg.datafile);
+  if (raw.size() > 80) raw = raw.substr(raw.size() - 80);
+  put_str(v, "rawdatafile");
+  put_str(v, raw);
+  std::string src(cfg.source);
+  if (src.size() > 80) src.resize(80);
+  put_str(v, "source_name");
+  put_str(v, src);
+  put_i(v, "barycentric", 0);
+  put_i(v, "pulsarcentric", 0);
+  put_d(v, "az_start", 0.0);
+  put_d(v, "za_start", 0.0);
+  put_d(v, "src_raj", sigproc_angle(cfg.ra));
+  put_d(v, "src_dej", sigproc_angle(cfg.dec));
+  put_d(v, "tstart", tstart_mjd);
+  put_d(v, "tsamp", pl.tsamp_s);
+  put_i(v, "nbits", cfg.nbit_out == -32 ? 32 : cfg.nbit_out);
+  put_d(v, "fch1", pl.fch1);
+  put_d(v, "foff", pl.foff);
+  put_i(v, "nchans", pl.c);
+  put_i(v, "nifs", pl.nif);
+  put_d(v, "refdm", cfg.dm);
+  put_str(v, "HEADER_END");
+  return v;
+}
+
+}  // namespace frbch
+
+// =============================================================================================
+// C ABI: configuration helpers (no GPU needed)
+// =============================================================================================
+using namespace frbch;
+
+static void set_err(char* err, size_t cap, const std::string& s) {
+  if (err && cap) snprintf(err, cap, "%s", s.c_str());
+}
+
+extern "C" int frbch_config_init(frbch_config* cfg) {
+  if (!cfg) return FRBCH_E_ARG;
+  memset(cfg, 0, sizeof(*cfg));
+  cfg->size = (uint32_t)sizeof(*cfg);
+  cfg->abi_version = FRBCH_ABI_VERSION;
+  cfg->freq_mhz = 1608.0;           // process_vdif.py:19
+  cfg->bw_mhz = 16.0;               // process_vdif.py:28
+  cfg->start_s = 0.0;
+  cfg->total_s = 1.0e30;            // digifil without -T: to end of data
+  cfg->nchan = 128;                 // run_digifil default (process_vdif.py:142)
+  cfg->freq_res = 0;
+  cfg->tscrunch = 1;
+  cfg->nbit_out = 8;
+  cfg->pol_mode = 2;
+  cfg->rescale_constant = 0;
+  cfg->rescale_interval_s = 10.0;   // digifil's default rescale interval
+  cfg->dm = 0.0;
+  cfg->coherent = 0;
+  cfg->device = 0;
+  snprintf(cfg->telescope, sizeof cfg->telescope, "ONSALA85");  // process_vdif.py:36
+  snprintf(cfg->source, sizeof cfg->source, "unknown");
+  snprintf(cfg->ra, sizeof cfg->ra, "00:00:00.0");
+  snprintf(cfg->dec, sizeof cfg->dec, "00:00:00.0");
+  return FRBCH_OK;
+}
+
+extern "C" int frbch_config_from_hdr(const char* hdr_path, frbch_config* cfg) {
+  if (!hdr_path || !cfg) return FRBCH_E_ARG;
+  std::ifstream f(hdr_path);
+  if (!f) return FRBCH_E_IO;
+  std::string line;
+  bool have_freq = false, have_bw = false, have_file = false, is_vdif = false;
+  while (std::getline(f, line)) {
+    std::istringstream ls(line);
+    std::string key;
+    if (!(ls >> key)) continue;
+    std::string val;
+    std::getline(ls, val);
+    const size_t b = val.find_first_not_of(" \t");
+    val = b == std::string::npos ? "" : val.substr(b);
+    while (!val.empty() && (val.back() == '\r' || val.back() == ' ' || val.back() == '\t')) val.pop_back();
+    if (key == "TELESCOPE") snprintf(cfg->telescope, sizeof cfg->telescope, "%s", val.c_str());
+    else if (key == "SOURCE") snprintf(cfg->source, sizeof cfg->source, "%s", val.c_str());
+    else if (key == "RA") snprintf(cfg->ra, sizeof cfg->ra, "%s", val.c_str());
+    else if (key == "DEC") snprintf(cfg->dec, sizeof cfg->dec, "%s", val.c_str());
+    else if (key == "FREQ") { cfg->freq_mhz = atof(val.c_str()); have_freq = true; }
+    else if (key == "BW") { cfg->bw_mhz = atof(val.c_str()); have_bw = true; }
+    else if (key == "DATAFILE") { snprintf(cfg->datafile, sizeof cfg->datafile, "%s", val.c_str()); have_file = true; }
+    else if (key == "INSTRUMENT") is_vdif = (val == "VDIF");
+    else if (key == "NPOL") { if (atoi(val.c_str()) != 2) return FRBCH_E_FORMAT; }
+  }
+  if (!have_freq || !have_bw || !have_file || !is_vdif) return FRBCH_E_FORMAT;
+  return FRBCH_OK;
+}
+
+// value of an option that may be attached ("-b8") or separate ("-t 8")
+static bool opt_value(const std::string& tok, size_t optlen, int argc, const char* const* argv, int* i,
+                      std::string* val) {
+  if (tok.size() > optlen) {
+    *val = tok.substr(optlen);
+    return true;
+  }
+  if (*i + 1 >= argc) return false;
+  *val = argv[++*i];
+  return true;
+}
+
+extern "C" int frbch_parse_digifil_argv(int argc, const char* const* argv, frbch_config* cfg,
+                                        char* hdr_path, size_t hdr_cap, char* out_path,
+                                        size_t out_cap, char* err, size_t err_cap) {
+  if (!cfg || !argv) return FRBCH_E_ARG;
+  std::string hdr, out, val;
+  for (int i = 1; i < argc; ++i) {
+    const std::string tok = argv[i];
+    if (tok.empty()) continue;
+    if (tok[0] != '-' || tok.size() == 1) {
+      if (!hdr.empty()) { set_err(err, err_cap, "more than one input file: " + tok); return FRBCH_E_ARG; }
+      hdr = tok;
+      continue;
+    }
+    bool ok = true;
+    if (tok == "-cont") continue;                       // contiguous input: what we assume anyway
+    else if (tok == "-c") cfg->rescale_constant = 1;
+    else if (tok == "-2") continue;                     // 2-bit excision off: static level table
+    else if (tok == "-threads") { ok = opt_value(tok, 8, argc, argv, &i, &val); }
+    else if (tok.compare(0, 2, "-b") == 0) { ok = opt_value(tok, 2, argc, argv, &i, &val); cfg->nbit_out = atoi(val.c_str()); }
+    else if (tok.compare(0, 2, "-S") == 0) { ok = opt_value(tok, 2, argc, argv, &i, &val); cfg->start_s = atof(val.c_str()); }
+    else if (tok.compare(0, 2, "-T") == 0) { ok = opt_value(tok, 2, argc, argv, &i, &val); cfg->total_s = atof(val.c_str()); }
+    else if (tok.compare(0, 2, "-D") == 0) { ok = opt_value(tok, 2, argc, argv, &i, &val); cfg->dm = atof(val.c_str()); }
+    else if (tok.compare(0, 2, "-t") == 0) { ok = opt_value(tok, 2, argc, argv, &i, &val); cfg->tscrunch = (uint32_t)atoi(val.c_str()); }
+    else if (tok.compare(0, 2, "-o") == 0) { ok = opt_value(tok, 2, argc, argv, &i, &out); }
+    else if (tok.compare(0, 2, "-I") == 0) { ok = opt_value(tok, 2, argc, argv, &i, &val); cfg->rescale_interval_s = atof(val.c_str()); }
+    else if (tok.compare(0, 2, "-P") == 0) {
+      ok = opt_value(tok, 2, argc, argv, &i, &val);
+      const int p = atoi(val.c_str());
+      if (p != 0 && p != 1) { set_err(err, err_cap, "-P must be 0 or 1"); return FRBCH_E_ARG; }
+      cfg->pol_mode = p;
+    } else if (tok.compare(0, 2, "-d") == 0) {
+      ok = opt_value(tok, 2, argc, argv, &i, &val);
+      const int d = atoi(val.c_str());
+      if (d == 1) cfg->pol_mode = 2;
+      else if (d == 3) cfg->pol_mode = 3;
+      else if (d == 4) cfg->pol_mode = 4;
+      else { set_err(err, err_cap, "-d" + val + " not implemented (choices: 1, 3, 4)"); return FRBCH_E_ARG; }
+    } else if (tok.compare(0, 2, "-F") == 0) {
+      ok = opt_value(tok, 2, argc, argv, &i, &val);
+      const size_t colon = val.find(':');
+      const int nch = atoi(val.substr(0, colon).c_str());
+      if (nch < 1) { set_err(err, err_cap, "bad -F " + val); return FRBCH_E_ARG; }
+      cfg->nchan = (uint32_t)nch;
+      if (colon != std::string::npos) {
+        const std::string rest = val.substr(colon + 1);
+        if (rest == "D") cfg->coherent = 1;
+        else {
+          const int fr = atoi(rest.c_str());
+          if (fr < 1) { set_err(err, err_cap, "bad -F " + val); return FRBCH_E_ARG; }
+          cfg->freq_res = (uint32_t)fr;
+          cfg->coherent = 0;
+        }
+      }
+    } else {
+      set_err(err, err_cap, "unknown option " + tok);
+      return FRBCH_E_ARG;
+    }
+    if (!ok) { set_err(err, err_cap, "option " + tok + " needs a value"); return FRBCH_E_ARG; }
+  }
+  if (hdr.empty()) { set_err(err, err_cap, "no input .hdr given"); return FRBCH_E_ARG; }
+  if (out.empty()) { set_err(err, err_cap, "no output file (-o) given"); return FRBCH_E_ARG; }
+  if (hdr_path && hdr_cap) snprintf(hdr_path, hdr_cap, "%s", hdr.c_str());
+  if (out_path && out_cap) snprintf(out_path, out_cap, "%s", out.c_str());
+  return FRBCH_OK;
+}
+
+extern "C" const char* frbch_strerror(int code) {
+  switch (code) {
+    case FRBCH_OK: return "ok";
+    case FRBCH_E_ARG: return "bad argument or unsupported configuration";
+    case FRBCH_E_IO: return "I/O error";
+    case FRBCH_E_FORMAT: return "unsupported or corrupt input format";
+    case FRBCH_E_DEVICE: return "GPU not available or HIP error (there is no CPU fallback)";
+    case FRBCH_E_NOMEM: return "out of memory";
+    case FRBCH_E_STATE: return "call sequence error";
+    case FRBCH_E_CAPACITY: return "output buffer too small";
+    default: return "unknown error";
+  }
+}

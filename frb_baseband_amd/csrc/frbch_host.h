@@ -1,0 +1,55 @@
+// Host-side (no GPU) pieces of libfrbch: formats, configuration, geometry planning.
+#ifndef FRBCH_HOST_H
+#define FRBCH_HOST_H
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/frbch.h"
+
+namespace frbch {
+
+struct VdifInfo {
+  uint32_t invalid, legacy, seconds, ref_epoch, frame_nr, log2_nchan, frame_bytes, is_complex,
+      bits_per_sample, thread_id, station_id;
+  uint32_t header_bytes() const { return legacy ? 16u : 32u; }
+  uint32_t payload_bytes() const { return frame_bytes - header_bytes(); }
+};
+
+// first 16 bytes of a frame -> fields (VDIF 1.1; geometry consumed at base2fil.sh:395-401)
+bool parse_vdif_header(const uint8_t* buf, VdifInfo* out);
+// checks that the stream is what spif2file writes for one IF (spif2file.sh:178-186)
+bool check_vdif_supported(const VdifInfo& v, std::string* why);
+int vdif_epoch_mjd(int ref_epoch);
+
+// geometry of one handle, derived from the configuration
+struct Plan {
+  int c, r, c2, log2_c2, log2_r, log2_n, log2_nlo;
+  int g, tt, tscr, nif, flip, nthreads;
+  uint64_t n;                 // samples per pol per block
+  uint64_t block_payload_bytes;
+  uint64_t rows_per_block;
+  uint64_t row_bytes;         // bytes per output row
+  uint64_t ncol;              // nif * C
+  uint64_t interval_rows;     // rescale interval in output rows; 0 = disabled
+  size_t k1_lds, k2_lds, kc_lds;
+  uint32_t maxb;              // blocks per launch
+  double rate_in;             // real samples / s / pol
+  double rate_out;            // output rows / s
+  double tsamp_s;
+  double fch1, foff;
+  float digi_mean, digi_scale, digi_max;
+};
+
+// returns "" on success, else the reason (InputError territory)
+std::string make_plan(const frbch_config& cfg, Plan* plan, size_t lds_limit);
+
+std::vector<uint8_t> sigproc_header(const frbch_config& cfg, const Plan& plan, double tstart_mjd);
+double sigproc_angle(const char* text);
+int sigproc_telescope_id(const char* name);
+
+// exp(-2 pi i k / n) for k in [0, count), evaluated in double, stored as float pairs
+void fill_twiddles(float* dst_xy, uint64_t n, uint64_t count, uint64_t step);
+
+}  // namespace frbch
+#endif

@@ -1,0 +1,71 @@
+// Kernel parameter block shared by the host side of the C-ABI library and the HIP kernels.
+#ifndef FRBCH_KPARAMS_H
+#define FRBCH_KPARAMS_H
+#include <stdint.h>
+
+struct __attribute__((aligned(8))) cf {  // complex float; 8-byte aligned so LDS traffic is b64
+  float x, y;
+};
+
+enum { FRBCH_OUT_FLOAT_POWER = 0, FRBCH_OUT_CODES = 1 };
+
+struct KParams {
+  // ---- geometry -------------------------------------------------------------------------
+  int log2_c2;        // log2(2C): length of the across-branch FFT
+  int log2_r;         // log2(R):  length of the along-branch FFTs
+  int c;              // nchan
+  int c2;             // 2C  = number of polyphase branches
+  int r;              // freq_res
+  int g;              // branches per K1 workgroup (power of two, divides 2C)
+  int tt;             // time samples per K2 sub-tile (power of two, divides R)
+  int tscr;           // tscrunch T (power of two, divides R)
+  int nif;            // 1 or 4 products
+  int pol_mode;       // 0,1,2,3,4
+  int nbit;           // 2, 8, 16, -32
+  int flip;           // 1 = USB input: reverse channel order on output
+  int out_mode;       // FRBCH_OUT_FLOAT_POWER / FRBCH_OUT_CODES
+  int log2_nlo;       // split of the N-point twiddle table: q = hi << log2_nlo | lo
+  // ---- VDIF frame stream ------------------------------------------------------------------
+  uint32_t frame_bytes, header_bytes, payload_bytes;
+  uint32_t pad0;
+  uint64_t payload_off;     // payload byte at which block 0 of this launch starts
+  const uint8_t* frames;
+  // ---- work buffers -------------------------------------------------------------------------
+  cf* spill;                // [nblk][2C/g][R][g]   delayed branch series w[n1][t]
+  cf* s_dc;                 // [nblk][2C]           S[n1] = sum_n2 p[n1 + 2C n2]
+  cf* p0;                   // [nblk][2C]           P[k'R] = FFT_2C(S)
+  const cf* tw_r;           // exp(-2 pi i k / R),  k < R/2
+  const cf* tw_c2;          // exp(-2 pi i k / 2C), k < C
+  const cf* tw_nhi;         // exp(-2 pi i (h << log2_nlo) / N)
+  const cf* tw_nlo;         // exp(-2 pi i l / N)
+  const float* offset;      // [nif][C], input channel order k
+  const float* scale;       // [nif][C]
+  float* power_out;         // [row][nif][C] float32, output channel order
+  uint8_t* code_out;        // [row][nif][C] packed to nbit, output channel order
+  uint64_t row0;            // first output row of block 0 of this launch inside *_out
+  float lut[4];             // 2-bit level table
+  float digi_mean, digi_scale, digi_max;
+  float pad1;
+};
+
+struct StatParams {
+  const float* power;       // [rows][ncol] (ncol = nif*C, output channel order)
+  double* partial;          // [nchunk][ncol][2]
+  uint64_t rows;            // rows that enter the statistics
+  uint64_t rows_per_chunk;
+  int ncol, c, nif, flip, nchunk;
+  float* offset;            // [nif][C] input channel order
+  float* scale;
+};
+
+struct QuantParams {
+  const float* power;       // [rows][ncol]
+  uint8_t* out;
+  uint64_t rows;
+  int ncol, c, nif, flip, nbit;
+  const float* offset;
+  const float* scale;
+  float digi_mean, digi_scale, digi_max;
+};
+
+#endif

@@ -1,0 +1,174 @@
+/* frbch.h -- C ABI of the MI355X VDIF -> SIGPROC-filterbank channeliser.
+ *
+ * Drop-in boundary.  The reference (pharaofranz/frb-baseband) has no FFI for this path: the
+ * boundary is a subprocess plus two files -- process_vdif.py:157-182 builds a `digifil` argv,
+ * :191 launches it, the input is the `.hdr` written by make_hdr (:115-139) whose DATAFILE is the
+ * per-IF VDIF, the output is the SIGPROC `.fil` named at :143-145 (possibly a FIFO,
+ * base2fil.sh:348-350).  Each entry point below cites the piece of that interface it replaces.
+ * Plain pointers and sizes only; no C++/torch types.  Handles are single-threaded, one per IF
+ * (base2fil.sh:60-66 runs one process per IF).  The library never calls exit().
+ *
+ * There is NO CPU fallback: every compute entry point needs a gfx950 device and fails with
+ * FRBCH_E_DEVICE otherwise.
+ */
+#ifndef FRBCH_H
+#define FRBCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FRBCH_ABI_VERSION 1
+
+/* error codes (negative); 0 = ok.  process_vdif.py:193-198 turns a non-zero digifil exit status
+ * into RunError; the CLI shim maps any of these to exit status 1 with frbch_strerror on stderr. */
+enum {
+  FRBCH_OK = 0,
+  FRBCH_E_ARG = -1,      /* bad argument / unsupported configuration (InputError territory)   */
+  FRBCH_E_IO = -2,       /* open/read/write failure                                           */
+  FRBCH_E_FORMAT = -3,   /* not the VDIF / .hdr we understand                                 */
+  FRBCH_E_DEVICE = -4,   /* no usable GPU, HIP error                                          */
+  FRBCH_E_NOMEM = -5,
+  FRBCH_E_STATE = -6,    /* call sequence error (e.g. pull before any push)                   */
+  FRBCH_E_CAPACITY = -7  /* caller buffer too small                                           */
+};
+
+/* pol_mode: what run_digifil maps --pol to (process_vdif.py:163-176):
+ *   0,1 -> -P0/-P1 single polarisation power; 2 -> -d1 PP+QQ; 3 -> -d3 (PP+QQ)^2;
+ *   4 -> -d4 PP,QQ,Re(PQ*),Im(PQ*)  (help text :58-64; base2fil.sh:214-217). */
+typedef struct frbch_config {
+  uint32_t size;               /* = sizeof(frbch_config); versioning                          */
+  uint32_t abi_version;        /* = FRBCH_ABI_VERSION                                         */
+  double freq_mhz;             /* .hdr FREQ (centre, process_vdif.py:127)                     */
+  double bw_mhz;               /* .hdr BW, signed: < 0 = LSB (process_vdif.py:117-118,128)    */
+  double start_s;              /* -S (process_vdif.py:157,160)                                */
+  double total_s;              /* -T                                                          */
+  uint32_t nchan;              /* -F<nchan>:...  (process_vdif.py:162-171)                    */
+  uint32_t freq_res;           /* -F...:<freq_res>; 0 = 512 if nchan<=128 else 2*nchan (:162) */
+  uint32_t tscrunch;           /* -t (only passed when > 1, process_vdif.py:156-158)          */
+  int32_t nbit_out;            /* -b: 2, 8, 16, -32 (process_vdif.py:153-155)                 */
+  int32_t pol_mode;            /* see above                                                   */
+  uint32_t rescale_constant;   /* -c (always passed, process_vdif.py:157,160)                 */
+  double rescale_interval_s;   /* -I secs; 0 = -I0 = keepBP (process_vdif.py:181-182)         */
+  double dm;                   /* -D (last one wins; header refdm; process_vdif.py:177-178)   */
+  uint32_t coherent;           /* -F<nchan>:D (process_vdif.py:179-180); not implemented yet  */
+  int32_t device;              /* GPU ordinal (>= 0)                                          */
+  uint32_t max_blocks_per_launch; /* 0 = auto; filterbank blocks batched per kernel launch    */
+  uint32_t reserved0;
+  char telescope[64];          /* .hdr TELESCOPE  (process_vdif.py:123)                       */
+  char source[64];             /* .hdr SOURCE     (:124)                                      */
+  char ra[32];                 /* .hdr RA         (:125)                                      */
+  char dec[32];                /* .hdr DEC        (:126)                                      */
+  char datafile[512];          /* .hdr DATAFILE   (:129)                                      */
+} frbch_config;
+
+typedef struct frbch_handle frbch_handle;
+
+/* geometry/result info, valid after frbch_open (time fields after the first frame was seen) */
+typedef struct frbch_info {
+  uint32_t size;
+  uint32_t nchan, freq_res, tscrunch, nif;
+  uint64_t block_samples;      /* N = 2*nchan*freq_res real samples per pol per block          */
+  uint64_t block_payload_bytes;/* N/2                                                          */
+  uint64_t rows_per_block;     /* freq_res / tscrunch output time samples per block            */
+  uint64_t row_bytes;          /* nif*nchan*|nbit|/8                                           */
+  uint64_t rescale_interval_rows; /* 0 = rescale disabled                                      */
+  uint64_t rows_out;           /* output time samples produced so far                          */
+  uint64_t blocks_done;
+  double tsamp_s;              /* nchan*tscrunch/|bw| us (create_config.py:561)                */
+  double tstart_mjd;
+  double fch1_mhz, foff_mhz;
+  uint32_t frame_bytes, header_bytes;
+  uint32_t have_rescale;       /* offset/scale are defined                                     */
+  uint32_t reserved;
+} frbch_info;
+
+/* per-kernel device time accumulated since the last frbch_timing_reset (HIP events recorded on
+ * the stream the kernels are launched on); enabled by frbch_set_profiling(h, 1). */
+typedef struct frbch_timing {
+  uint32_t size;
+  uint32_t nkernels;
+  struct {
+    char name[32];
+    uint64_t launches;
+    double total_ms;
+    double algorithmic_bytes;  /* sum over launches of the DESIGN.md per-launch byte model      */
+  } k[8];
+} frbch_timing;
+
+/* ---- configuration helpers ------------------------------------------------------------- */
+/* defaults = digifil's as the reference relies on them (nbit 8, -d1, 10 s rescale interval) */
+int frbch_config_init(frbch_config* cfg);
+/* parse the ASCII side file make_hdr writes (process_vdif.py:115-139, keys :122-133) */
+int frbch_config_from_hdr(const char* hdr_path, frbch_config* cfg);
+/* parse the digifil argv run_digifil builds (process_vdif.py:156-182):
+ * -cont -c -b<n> -S<s> -T<s> -2 -D <dm> [-t <T>] -o <out> <hdr> -threads <n>
+ * (-P<p> | -d<n>) -F<C>:<R|D> [-I<secs>]; -D and -F may repeat, last wins.  argv[0] is skipped.
+ * hdr_path/out_path receive the positional .hdr and the -o value. */
+int frbch_parse_digifil_argv(int argc, const char* const* argv, frbch_config* cfg,
+                             char* hdr_path, size_t hdr_cap, char* out_path, size_t out_cap,
+                             char* err, size_t err_cap);
+
+/* ---- lifecycle --------------------------------------------------------------------------- */
+int frbch_open(const frbch_config* cfg, frbch_handle** out);   /* replaces: digifil start-up  */
+void frbch_close(frbch_handle* h);
+const char* frbch_last_error(frbch_handle* h);                 /* replaces: digifil's stderr  */
+const char* frbch_strerror(int code);
+int frbch_get_info(frbch_handle* h, frbch_info* info);
+
+/* ---- whole-file path: what `digifil ... -o <out> <hdr>` does (process_vdif.py:191) ---------
+ * Reads cfg.datafile-style VDIF at `vdif_path`, honours -S/-T, writes SIGPROC header + samples to
+ * `out_fil` strictly sequentially.  out_fil may be an existing FIFO: opened
+ * O_WRONLY|O_CREAT|O_TRUNC without O_EXCL (INSTALL.md:32-35), never unlinked, never seeked. */
+int frbch_run_file(frbch_handle* h, const char* vdif_path, const char* out_fil);
+
+/* ---- streaming host path ----------------------------------------------------------------- */
+/* push whole or partial frames (byte stream starting at a frame boundary on the first call) */
+int frbch_push(frbch_handle* h, const uint8_t* frames, size_t nbytes);
+/* signal end of input: flushes a pending rescale interval */
+int frbch_flush(frbch_handle* h);
+/* copy out quantised [t][nif][chan] rows that are ready; returns bytes written, <0 on error */
+long frbch_pull(frbch_handle* h, uint8_t* dst, size_t cap);
+/* SIGPROC header bytes for the stream (valid once the first frame has been seen) */
+long frbch_sigproc_header(frbch_handle* h, uint8_t* dst, size_t cap);
+
+/* ---- device-resident path (inputs and outputs already in HBM) ----------------------------- */
+/* d_frames: device pointer to whole VDIF frames (frame geometry taken from `frame_bytes`,
+ * `header_bytes`); the payload stream is entered `payload_byte_offset` bytes after the first
+ * payload byte (must be a multiple of 4); `nblocks` filterbank blocks are transformed.
+ * d_out receives rows_per_block*nblocks rows of row_bytes (fewer while a rescale interval is still
+ * being measured; *rows_written says how many).  `stream` is a hipStream_t (NULL = the handle's
+ * own stream).  Asynchronous with respect to the host except when a rescale interval completes. */
+int frbch_process_device(frbch_handle* h, const void* d_frames, size_t nframes,
+                         uint32_t frame_bytes, uint32_t header_bytes, uint64_t payload_byte_offset,
+                         uint64_t nblocks, void* d_out, size_t out_cap_bytes,
+                         uint64_t* rows_written, void* stream);
+/* finish a pending rescale interval into d_out (device) */
+int frbch_flush_device(frbch_handle* h, void* d_out, size_t out_cap_bytes, uint64_t* rows_written,
+                       void* stream);
+/* detected + scrunched power of `nblocks` blocks as float32 [t][nif][chan] (channel order of the
+ * output file), no rescale/digitise: the "-b-32 -I0" data product and the parity-test tap. */
+int frbch_power_device(frbch_handle* h, const void* d_frames, size_t nframes, uint32_t frame_bytes,
+                       uint32_t header_bytes, uint64_t payload_byte_offset, uint64_t nblocks,
+                       float* d_power, size_t cap_bytes, void* stream);
+
+/* ---- rescale state (the one stateful stage; SURVEY 7 hard part 6) ------------------------- */
+/* offset/scale are [nif][nchan] in INPUT channel order k (ascending FFT bin), float32 */
+int frbch_get_rescale(frbch_handle* h, float* offset, float* scale);
+int frbch_set_rescale(frbch_handle* h, const float* offset, const float* scale);
+
+/* ---- measurement -------------------------------------------------------------------------- */
+int frbch_set_profiling(frbch_handle* h, int enable);
+int frbch_timing_reset(frbch_handle* h);
+int frbch_get_timing(frbch_handle* h, frbch_timing* t);
+
+/* library self-description: "frbch <abi> gfx950 ..." */
+const char* frbch_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRBCH_H */

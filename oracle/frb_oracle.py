@@ -1,0 +1,423 @@
+"""CPU oracle (numpy, fp64) for the VDIF -> SIGPROC-filterbank channeliser path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is imported, linked or executed by the
+product path (``frb_baseband_amd``); only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may use it, and only as the checker.
+
+PARITY UNPINNED (numerical stages).  The reference (pharaofranz/frb-baseband) contains no
+numerical code: the arithmetic lives in DSPSR's ``digifil``, which the reference launches as a
+subprocess (process_vdif.py:157-191).  DSPSR is an un-vendored, un-pinned third-party dependency
+(README.md:8; fallback commit b68528e15e8, INSTALL.md:37-39), absent from /root/reference and from
+this image, and the reference ships no tests or golden outputs for it.  This file therefore
+restates digifil's *published* stage chain as selected by the flags the reference passes
+(process_vdif.py:156-182) and anchors on the reference's own call sites:
+
+  stage                      reference anchor (file:line)                      function here
+  -------------------------  -----------------------------------------------   ---------------------
+  .hdr ASCII side file       process_vdif.py:115-139 (keys :122-133)           read_hdr
+  VDIF frame geometry        base2fil.sh:130-147,395-401; spif2file.sh:181     parse_vdif_header, strip_frames
+  2-bit unpack  (-2)         process_vdif.py:157,160; spif2file.sh:34          unpack_2bit
+  filterbank    (-F C:R)     process_vdif.py:162-171                           filterbank_block
+  detection     (-d/-P)      process_vdif.py:58-64,163-176; base2fil.sh:214-7  detect
+  time scrunch  (-t)         process_vdif.py:156-158                           tscrunch
+  rescale       (-c, -I0)    process_vdif.py:157,160,181-182; frb.conf:51      rescale_stats, rescale_apply
+  digitise      (-b)         process_vdif.py:65-68,153-155                     digitise
+  SIGPROC output (-o)        process_vdif.py:143-145; base2fil.sh:422          sigproc_header, channelise
+  resolution identity        create_config.py:561                               (checked in tests)
+
+The harness part of the path (make_hdr / run_digifil argv mapping) IS pinned: golden strings are
+captured by importing the reference's process_vdif.py (tests/golden/make_harness_golden.py).
+
+Conventions fixed here (each is a statement of DSPSR's documented behaviour, unverifiable in this
+image, see DESIGN.md "Oracle"):
+  * real-sampled input, N = 2*C*R samples per pol per block; forward real FFT (unnormalised);
+    channel k owns bins [k*R, (k+1)*R) (Nyquist bin dropped); backward complex FFT of length R
+    (unnormalised) gives R time samples of channel k; no overlap when not dedispersing.
+  * only whole blocks are transformed; the tail that does not fill a block is dropped.
+  * 2-bit offset-binary levels 0..3 -> (-3.3359, -1, +1, +3.3359) (static table).
+  * rescale: per (product, channel) offset = -mean, scale = 1/sqrt(variance) (population variance)
+    over the first ``interval`` output samples (default 10 s worth, clipped to what exists);
+    with -c the pair is then frozen; without -c it is recomputed per interval; -I0 disables.
+  * digitise: int(x*scale_n + mean_n + 0.5) clipped to [0, 2^n - 1], with (mean_n, scale_n) =
+    (1.5, 1) for 2 bit, (127.5, 127.5/6) for 8 bit, (32767.5, 32767.5/6) for 16 bit; -32 = float32.
+  * output order: time-major [t][product][channel], channels in DESCENDING sky frequency
+    (foff < 0): USB input (BW > 0) is flipped, LSB input (BW < 0) is already descending.
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass, field
+
+import numpy as np
+
+LEVELS_2BIT = np.array([-3.3359, -1.0, 1.0, 3.3359], dtype=np.float64)
+DIGI_SIGMA = 6.0
+DEFAULT_RESCALE_INTERVAL_S = 10.0
+MJD_2000 = 51544  # MJD of 2000-01-01, the VDIF epoch-0 reference
+
+
+# --------------------------------------------------------------------------------------------
+# .hdr side file (process_vdif.py:122-133)
+# --------------------------------------------------------------------------------------------
+def read_hdr(path: str) -> dict:
+    """Parse the 12-line DSPSR ASCII header written by make_hdr (process_vdif.py:115-139)."""
+    out = {}
+    with open(path, "r") as f:
+        for line in f.read().splitlines():
+            parts = line.split(None, 1)
+            if len(parts) == 2:
+                out[parts[0]] = parts[1].strip()
+    for key in ("FREQ", "BW"):
+        out[key] = float(out[key])
+    out["NPOL"] = int(out.get("NPOL", 2))
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# VDIF frames (public VDIF 1.1 layout; geometry used at base2fil.sh:395-401)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class VdifHeader:
+    invalid: int
+    legacy: int
+    seconds: int
+    ref_epoch: int
+    frame_nr: int
+    version: int
+    log2_nchan: int
+    frame_bytes: int
+    is_complex: int
+    bits_per_sample: int
+    thread_id: int
+    station_id: int
+
+    @property
+    def header_bytes(self) -> int:
+        return 16 if self.legacy else 32
+
+    @property
+    def payload_bytes(self) -> int:
+        return self.frame_bytes - self.header_bytes
+
+
+def parse_vdif_header(buf: bytes) -> VdifHeader:
+    w0, w1, w2, w3 = struct.unpack_from("<4I", buf, 0)
+    return VdifHeader(
+        invalid=(w0 >> 31) & 1, legacy=(w0 >> 30) & 1, seconds=w0 & 0x3FFFFFFF,
+        ref_epoch=(w1 >> 24) & 0x3F, frame_nr=w1 & 0xFFFFFF,
+        version=(w2 >> 29) & 0x7, log2_nchan=(w2 >> 24) & 0x1F, frame_bytes=(w2 & 0xFFFFFF) * 8,
+        is_complex=(w3 >> 31) & 1, bits_per_sample=((w3 >> 26) & 0x1F) + 1,
+        thread_id=(w3 >> 16) & 0x3FF, station_id=w3 & 0xFFFF)
+
+
+def vdif_epoch_mjd(ref_epoch: int) -> int:
+    """MJD of the VDIF reference epoch (6-month steps from 2000-01-01)."""
+    year = 2000 + ref_epoch // 2
+    month = 1 if ref_epoch % 2 == 0 else 7
+    # days from civil (proleptic Gregorian) -> MJD
+    a = (14 - month) // 12
+    y = year + 4800 - a
+    m = month + 12 * a - 3
+    jdn = 1 + (153 * m + 2) // 5 + 365 * y + y // 4 - y // 100 + y // 400 - 32045
+    return jdn - 2400001
+
+
+def strip_frames(raw: np.ndarray, frame_bytes: int, header_bytes: int) -> np.ndarray:
+    """Drop frame headers; ``raw`` is a whole number of frames (uint8)."""
+    nfr = raw.size // frame_bytes
+    return raw[: nfr * frame_bytes].reshape(nfr, frame_bytes)[:, header_bytes:].reshape(-1)
+
+
+# --------------------------------------------------------------------------------------------
+# 2-bit unpack (A4): byte -> 4 floats
+# --------------------------------------------------------------------------------------------
+def unpack_2bit(payload: np.ndarray) -> np.ndarray:
+    """u8[nbytes] -> f64[2][2*nbytes].
+
+    2-channel (= 2 pol), 2-bit VDIF: bits[1:0]=pol0 t, [3:2]=pol1 t, [5:4]=pol0 t+1,
+    [7:6]=pol1 t+1 (channel-interleaved, LSB first; recipe brackets at spif2file.sh:34 list
+    2 pols x 2 bits per IF).
+    """
+    b = payload.astype(np.uint8)
+    out = np.empty((2, b.size * 2), dtype=np.float64)
+    out[0, 0::2] = LEVELS_2BIT[b & 3]
+    out[1, 0::2] = LEVELS_2BIT[(b >> 2) & 3]
+    out[0, 1::2] = LEVELS_2BIT[(b >> 4) & 3]
+    out[1, 1::2] = LEVELS_2BIT[(b >> 6) & 3]
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# Filterbank (A5 + A6): -F C:R
+# --------------------------------------------------------------------------------------------
+def freq_res_for(nchan: int) -> int:
+    """leakage factor rule of process_vdif.py:162."""
+    return 512 if nchan <= 128 else 2 * nchan
+
+
+def filterbank_block(x: np.ndarray, nchan: int, freq_res: int) -> np.ndarray:
+    """f64[npol][N] -> c128[npol][nchan][freq_res], N = 2*nchan*freq_res.
+
+    Forward real FFT of N samples, spectrum cut into nchan slices of freq_res bins, backward
+    complex FFT (unnormalised) per slice.
+    """
+    npol, n = x.shape
+    assert n == 2 * nchan * freq_res
+    spec = np.fft.rfft(x, axis=1)[:, : nchan * freq_res]          # drop Nyquist
+    spec = spec.reshape(npol, nchan, freq_res)
+    return np.fft.ifft(spec, axis=2) * freq_res                   # unnormalised backward
+
+
+# --------------------------------------------------------------------------------------------
+# Detection (A7): -P0/-P1/-d1/-d3/-d4
+# --------------------------------------------------------------------------------------------
+def nif_for(pol_mode: int) -> int:
+    return 4 if pol_mode == 4 else 1
+
+
+def detect(y: np.ndarray, pol_mode: int) -> np.ndarray:
+    """c128[2][C][R] -> f64[nif][C][R]  (semantics: process_vdif.py:58-64, base2fil.sh:214-217).
+
+    0/1: |p|^2 of that pol; 2: PP+QQ; 3: (PP+QQ)^2; 4: PP, QQ, Re(p0 p1*), Im(p0 p1*).
+    """
+    pp = y[0].real ** 2 + y[0].imag ** 2
+    qq = y[1].real ** 2 + y[1].imag ** 2
+    if pol_mode == 0:
+        return pp[None]
+    if pol_mode == 1:
+        return qq[None]
+    if pol_mode == 2:
+        return (pp + qq)[None]
+    if pol_mode == 3:
+        return ((pp + qq) ** 2)[None]
+    if pol_mode == 4:
+        pq = y[0] * np.conj(y[1])
+        return np.stack([pp, qq, pq.real, pq.imag])
+    raise ValueError(f"pol = {pol_mode} not implemented. Choices are 0, 1, 2, 3, 4")
+
+
+# --------------------------------------------------------------------------------------------
+# Time scrunch (A8): -t T
+# --------------------------------------------------------------------------------------------
+def tscrunch(p: np.ndarray, factor: int) -> np.ndarray:
+    """f64[nif][C][nt] -> f64[nif][C][nt // factor]  (sum of `factor` adjacent samples)."""
+    if factor <= 1:
+        return p
+    nif, c, nt = p.shape
+    nt2 = nt // factor
+    return p[:, :, : nt2 * factor].reshape(nif, c, nt2, factor).sum(axis=3)
+
+
+# --------------------------------------------------------------------------------------------
+# Rescale (A9): -c / -I
+# --------------------------------------------------------------------------------------------
+def rescale_stats(p: np.ndarray):
+    """f64[nif][C][nt] -> (offset[nif][C], scale[nif][C]); offset=-mean, scale=1/sigma."""
+    mean = p.mean(axis=2)
+    var = (p * p).mean(axis=2) - mean * mean
+    scale = np.where(var > 0.0, 1.0 / np.sqrt(np.where(var > 0.0, var, 1.0)), 1.0)
+    return -mean, scale
+
+
+def rescale_apply(p: np.ndarray, offset: np.ndarray, scale: np.ndarray) -> np.ndarray:
+    return (p + offset[:, :, None]) * scale[:, :, None]
+
+
+# --------------------------------------------------------------------------------------------
+# Digitise (A10): -b {2,8,16,-32}
+# --------------------------------------------------------------------------------------------
+def digi_params(nbit: int):
+    if nbit == 2:
+        return 1.5, 1.0, 3
+    if nbit == 8:
+        return 127.5, 127.5 / DIGI_SIGMA, 255
+    if nbit == 16:
+        return 32767.5, 32767.5 / DIGI_SIGMA, 65535
+    if nbit == -32:
+        return 0.0, 1.0, None
+    raise ValueError(f"nbit={nbit} not in supported values of [2, 8, 16, -32]. ")
+
+
+def digitise_values(x: np.ndarray, nbit: int) -> np.ndarray:
+    """Rescaled floats -> integer codes (before bit packing); float32 for -32."""
+    mean, scale, vmax = digi_params(nbit)
+    if nbit == -32:
+        return x.astype(np.float32)
+    # the arithmetic is stated in fp32 (the stage is fp32 in the reference's engine)
+    v = x.astype(np.float32) * np.float32(scale) + np.float32(mean + 0.5)
+    v = np.clip(np.trunc(v), 0, vmax)
+    return v.astype(np.uint16 if nbit == 16 else np.uint8)
+
+
+def pack_codes(codes: np.ndarray, nbit: int) -> bytes:
+    """codes in output order (flattened [t][nif][chan]) -> byte stream. 2-bit: 4 per byte LSB first."""
+    flat = codes.reshape(-1)
+    if nbit == 2:
+        assert flat.size % 4 == 0
+        q = flat.reshape(-1, 4).astype(np.uint8)
+        return (q[:, 0] | (q[:, 1] << 2) | (q[:, 2] << 4) | (q[:, 3] << 6)).astype(np.uint8).tobytes()
+    if nbit == 8:
+        return flat.astype(np.uint8).tobytes()
+    if nbit == 16:
+        return flat.astype("<u2").tobytes()
+    return flat.astype("<f4").tobytes()
+
+
+# --------------------------------------------------------------------------------------------
+# SIGPROC header (A10, public sigproc format)
+# --------------------------------------------------------------------------------------------
+SIGPROC_TELESCOPE_ID = {
+    "fake": 0, "arecibo": 1, "ooty": 2, "nancay": 3, "parkes": 4, "jodrell": 5, "gbt": 6,
+    "gmrt": 7, "effelsberg": 8, "ata": 9, "srt": 10, "lofar": 11, "vla": 12,
+}
+
+
+def _sp_str(s: str) -> bytes:
+    b = s.encode("ascii")
+    return struct.pack("<i", len(b)) + b
+
+
+def sigproc_ra_dec(text: str) -> float:
+    """'hh:mm:ss.ss' / 'dd:mm:ss.ss' -> sigproc packed double (hhmmss.ss)."""
+    t = text.strip()
+    sign = -1.0 if t.startswith("-") else 1.0
+    t = t.lstrip("+-")
+    parts = t.split(":")
+    parts += ["0"] * (3 - len(parts))
+    return sign * (float(parts[0]) * 10000.0 + float(parts[1]) * 100.0 + float(parts[2]))
+
+
+def sigproc_header(*, telescope: str, source: str, ra: str, dec: str, rawdatafile: str,
+                   tstart_mjd: float, tsamp_s: float, nbits: int, fch1: float, foff: float,
+                   nchans: int, nifs: int, refdm: float = 0.0) -> bytes:
+    h = _sp_str("HEADER_START")
+    h += _sp_str("telescope_id") + struct.pack("<i", SIGPROC_TELESCOPE_ID.get(telescope.lower(), 0))
+    h += _sp_str("machine_id") + struct.pack("<i", 0)
+    h += _sp_str("data_type") + struct.pack("<i", 1)
+    h += _sp_str("rawdatafile") + _sp_str(rawdatafile[-80:])
+    h += _sp_str("source_name") + _sp_str(source[:80])
+    h += _sp_str("barycentric") + struct.pack("<i", 0)
+    h += _sp_str("pulsarcentric") + struct.pack("<i", 0)
+    h += _sp_str("az_start") + struct.pack("<d", 0.0)
+    h += _sp_str("za_start") + struct.pack("<d", 0.0)
+    h += _sp_str("src_raj") + struct.pack("<d", sigproc_ra_dec(ra))
+    h += _sp_str("src_dej") + struct.pack("<d", sigproc_ra_dec(dec))
+    h += _sp_str("tstart") + struct.pack("<d", tstart_mjd)
+    h += _sp_str("tsamp") + struct.pack("<d", tsamp_s)
+    h += _sp_str("nbits") + struct.pack("<i", 32 if nbits == -32 else nbits)
+    h += _sp_str("fch1") + struct.pack("<d", fch1)
+    h += _sp_str("foff") + struct.pack("<d", foff)
+    h += _sp_str("nchans") + struct.pack("<i", nchans)
+    h += _sp_str("nifs") + struct.pack("<i", nifs)
+    h += _sp_str("refdm") + struct.pack("<d", refdm)
+    h += _sp_str("HEADER_END")
+    return h
+
+
+def channel_freqs(freq_mhz: float, bw_mhz: float, nchan: int):
+    """(fch1, foff) of the OUTPUT order (descending sky frequency)."""
+    df = abs(bw_mhz) / nchan
+    top_edge = freq_mhz + abs(bw_mhz) / 2.0
+    return top_edge - df / 2.0, -df
+
+
+# --------------------------------------------------------------------------------------------
+# Whole path
+# --------------------------------------------------------------------------------------------
+@dataclass
+class Config:
+    freq_mhz: float = 1608.0
+    bw_mhz: float = 16.0            # signed: negative = LSB (process_vdif.py:117-118)
+    start_s: float = 0.0            # -S
+    total_s: float = 10.0           # -T
+    nchan: int = 128                # -F C:
+    freq_res: int = 0               # -F :R   (0 -> rule of process_vdif.py:162)
+    tscrunch: int = 1               # -t
+    nbit: int = 8                   # -b
+    pol_mode: int = 2               # -P0/-P1 -> 0/1 ; -d1 -> 2 ; -d3 -> 3 ; -d4 -> 4
+    rescale_constant: bool = True   # -c
+    rescale_interval_s: float = DEFAULT_RESCALE_INTERVAL_S  # -I ; 0 = disabled
+    dm: float = 0.0
+    telescope: str = "ONSALA85"
+    source: str = "J0000+0000"
+    ra: str = "00:00:00.0"
+    dec: str = "00:00:00.0"
+    rawdatafile: str = ""
+    fixed_offset: np.ndarray | None = None   # set_rescale equivalent
+    fixed_scale: np.ndarray | None = None
+    result: dict = field(default_factory=dict)
+
+
+def detected_power(raw_frames: np.ndarray, cfg: Config):
+    """Frames (uint8, starting at a frame boundary) -> f64[nif][C][nt] after tscrunch, plus header.
+
+    Applies -S / -T (whole seconds counted in samples), drops the partial last block.
+    """
+    hdr = parse_vdif_header(raw_frames[:32].tobytes())
+    payload = strip_frames(raw_frames, hdr.frame_bytes, hdr.header_bytes)
+    rate = 2.0e6 * abs(cfg.bw_mhz)                    # real samples / s / pol
+    c = cfg.nchan
+    r = cfg.freq_res or freq_res_for(c)
+    n = 2 * c * r
+    s0 = int(round(cfg.start_s * rate))
+    s0 -= s0 % 2                                      # byte aligned (2 time samples per byte)
+    navail = payload.size * 2 - s0
+    nwant = int(round(cfg.total_s * rate))
+    nsamp = max(0, min(navail, nwant))
+    nblocks = nsamp // n
+    x = unpack_2bit(payload[s0 // 2: s0 // 2 + nblocks * n // 2])
+    out = []
+    for b in range(nblocks):
+        y = filterbank_block(x[:, b * n:(b + 1) * n], c, r)
+        out.append(detect(y, cfg.pol_mode))
+    nif = nif_for(cfg.pol_mode)
+    p = np.concatenate(out, axis=2) if out else np.zeros((nif, c, 0))
+    return tscrunch(p, cfg.tscrunch), hdr, s0, r
+
+
+def channelise(raw_frames: np.ndarray, cfg: Config) -> bytes:
+    """Whole path: frames -> SIGPROC .fil bytes (header + samples)."""
+    p, hdr, s0, r = detected_power(raw_frames, cfg)
+    nif, c, nt = p.shape
+    tsamp_s = c * cfg.tscrunch / (abs(cfg.bw_mhz) * 1.0e6)
+    rate = 2.0e6 * abs(cfg.bw_mhz)
+    fps = rate * 2 * 2 / 8 / hdr.payload_bytes        # frames per second for 2 pol x 2 bit
+    tstart = (vdif_epoch_mjd(hdr.ref_epoch)
+              + (hdr.seconds + hdr.frame_nr / fps + s0 / rate) / 86400.0)
+
+    offset = np.zeros((nif, c))
+    scale = np.ones((nif, c))
+    if cfg.fixed_offset is not None:
+        offset, scale = cfg.fixed_offset.astype(np.float64), cfg.fixed_scale.astype(np.float64)
+        x = rescale_apply(p, offset, scale)
+    elif cfg.rescale_interval_s > 0 and nt > 0:
+        rate_out = abs(cfg.bw_mhz) * 1.0e6 / (c * cfg.tscrunch)     # output samples per second
+        nint = max(1, int(cfg.rescale_interval_s * rate_out))       # truncation, as a uint64 cast
+        x = np.empty_like(p)
+        for i0 in range(0, nt, nint):
+            seg = p[:, :, i0:i0 + nint]
+            if i0 == 0 or not cfg.rescale_constant:
+                offset, scale = rescale_stats(seg)
+            x[:, :, i0:i0 + nint] = rescale_apply(seg, offset, scale)
+            if i0 == 0:
+                cfg.result["offset0"], cfg.result["scale0"] = offset.copy(), scale.copy()
+    else:
+        x = p
+    cfg.result["power"] = p
+    cfg.result["rescaled"] = x
+
+    if cfg.bw_mhz > 0:                                # USB: flip so that foff < 0
+        x = x[:, ::-1, :]
+    codes = digitise_values(np.ascontiguousarray(x.transpose(2, 0, 1)), cfg.nbit)  # [t][nif][chan]
+    cfg.result["codes"] = codes
+    fch1, foff = channel_freqs(cfg.freq_mhz, cfg.bw_mhz, c)
+    head = sigproc_header(telescope=cfg.telescope, source=cfg.source, ra=cfg.ra, dec=cfg.dec,
+                          rawdatafile=cfg.rawdatafile, tstart_mjd=tstart, tsamp_s=tsamp_s,
+                          nbits=cfg.nbit, fch1=fch1, foff=foff, nchans=c, nifs=nif, refdm=cfg.dm)
+    return head + pack_codes(codes, cfg.nbit)
+
+
+def config_from_hdr(hdr_path: str, **kw) -> Config:
+    h = read_hdr(hdr_path)
+    return Config(freq_mhz=h["FREQ"], bw_mhz=h["BW"], telescope=h["TELESCOPE"],
+                  source=h["SOURCE"], ra=h["RA"], dec=h["DEC"], rawdatafile=h["DATAFILE"], **kw)

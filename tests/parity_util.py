@@ -1,0 +1,81 @@
+"""Shared parity checks: HIP path (or the test-only emulator) against the fp64 oracle."""
+import numpy as np
+
+from frb_baseband_amd import channeliser as ch
+from frb_baseband_amd import sigproc, synth
+from oracle import frb_oracle as o
+
+# Tolerances (stated, see DESIGN.md "Parity"):
+#  * detected power: |P - P_oracle| <= POWER_RTOL * mean power of that (product, channel) series
+#    (fp32 FFT of up to 2^26 points against an fp64 oracle).
+#  * digitised codes: identical except where the oracle's pre-rounding value lies within
+#    CODE_TIE_EPS of a rounding boundary; such samples may differ by 1 and must stay below
+#    CODE_MISMATCH_FRAC of all samples.
+POWER_RTOL = 2e-5
+CODE_TIE_EPS = 2e-3
+CODE_MISMATCH_FRAC = 2e-4
+RESCALE_RTOL = 2e-6
+
+
+def make_case(bw, nchan, secs, **kw):
+    raw = synth.make_vdif(secs, bw_mhz=abs(bw), nchan=nchan, **{k: kw.pop(k) for k in list(kw) if k in ("payload_bytes", "legacy", "if_index")})
+    return raw
+
+
+def oracle_cfg(bw, nchan, secs, pol=2, nbit=8, tscr=1, interval=10.0, const=1, freq_res=0, start=0.0):
+    return o.Config(bw_mhz=bw, nchan=nchan, total_s=secs, start_s=start, pol_mode=pol, nbit=nbit,
+                    tscrunch=tscr, rescale_interval_s=interval, rescale_constant=bool(const),
+                    freq_res=freq_res, source="unknown", telescope="ONSALA85")
+
+
+def lib_cfg(lib, bw, nchan, secs, pol=2, nbit=8, tscr=1, interval=10.0, const=1, freq_res=0, start=0.0, maxb=0):
+    return ch.new_config(lib, bw_mhz=bw, nchan=nchan, total_s=secs, start_s=start, pol_mode=pol,
+                         nbit_out=nbit, tscrunch=tscr, rescale_interval_s=interval,
+                         rescale_constant=const, freq_res=freq_res, max_blocks_per_launch=maxb)
+
+
+def expected_boundary_distance(ocfg):
+    """distance of the oracle's pre-rounding value t+0.5 from the nearest integer, per output sample"""
+    mean, scale, vmax = o.digi_params(ocfg.nbit)
+    x = ocfg.result["rescaled"]
+    if ocfg.bw_mhz > 0:
+        x = x[:, ::-1, :]
+    t = x.transpose(2, 0, 1) * scale + mean + 0.5
+    return np.abs(t - np.round(t))
+
+
+def check_codes(ref_bytes, got_bytes, ocfg):
+    fr = sigproc.read_fil(ref_bytes)
+    fg = sigproc.read_fil(got_bytes)
+    assert ref_bytes[:fr.header_bytes] == got_bytes[:fg.header_bytes], "SIGPROC header differs"
+    assert fr.data.shape == fg.data.shape
+    if ocfg.nbit == -32:
+        ref = fr.data.astype(np.float64)
+        np.testing.assert_allclose(fg.data, ref, rtol=0, atol=POWER_RTOL * 50 * max(1.0, np.abs(ref).max()))
+        return 0
+    d = fg.data.astype(np.int64) - fr.data.astype(np.int64)
+    bad = np.nonzero(d)
+    nbad = bad[0].size
+    if nbad:
+        assert np.abs(d).max() <= 1, "code differs by more than 1"
+        dist = expected_boundary_distance(ocfg)[bad]
+        assert dist.max() <= CODE_TIE_EPS, f"mismatch away from a rounding tie: {dist.max()}"
+        assert nbad <= max(2, CODE_MISMATCH_FRAC * d.size), f"{nbad} of {d.size} codes differ"
+    return nbad
+
+
+def run_streaming_case(lib, bw, nchan, secs, **kw):
+    """oracle .fil vs library .fil through push/flush/pull; returns mismatch count"""
+    raw = synth.make_vdif(secs + kw.get("start", 0.0), bw_mhz=abs(bw), nchan=nchan)
+    ocfg = oracle_cfg(bw, nchan, secs, **{k: v for k, v in kw.items() if k != "maxb"})
+    ref = o.channelise(raw, ocfg)
+    cfg = lib_cfg(lib, bw, nchan, secs, **kw)
+    with ch.Channeliser(cfg, lib) as c:
+        got = c.channelise_bytes(raw)
+        resc = c.get_rescale() if c.get_info().have_rescale else None
+    nbad = check_codes(ref, got, ocfg)
+    if resc is not None and kw.get("interval", 10.0) > 0 and kw.get("const", 1) and "offset0" in ocfg.result:
+        off0, sc0 = ocfg.result["offset0"], ocfg.result["scale0"]
+        assert np.abs(resc[0] - off0).max() <= RESCALE_RTOL * np.abs(off0).max()
+        np.testing.assert_allclose(resc[1], sc0, rtol=RESCALE_RTOL)
+    return nbad
