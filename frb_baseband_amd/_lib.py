@@ -68,6 +68,7 @@ SYMBOLS = {
     "frbch_last_error": (C.c_char_p, [_P]),
     "frbch_strerror": (C.c_char_p, [C.c_int]),
     "frbch_get_info": (C.c_int, [_P, C.POINTER(FrbchInfo)]),
+    "frbch_reset": (C.c_int, [_P]),
     "frbch_run_file": (C.c_int, [_P, C.c_char_p, C.c_char_p]),
     "frbch_push": (C.c_int, [_P, _P, C.c_size_t]),
     "frbch_flush": (C.c_int, [_P]),

@@ -83,6 +83,9 @@ class Channeliser:
         self._check(self.lib.frbch_get_info(self._h, C.byref(info)))
         return info
 
+    def reset(self) -> None:
+        self._check(self.lib.frbch_reset(self._h))
+
     # -- whole file (what `digifil ... -o out hdr` does) ----------------------------------------
     def run_file(self, vdif_path: str, out_fil: str):
         self._check(self.lib.frbch_run_file(self._h, vdif_path.encode(), out_fil.encode()))

@@ -443,6 +443,24 @@ extern "C" int frbch_get_info(frbch_handle* h, frbch_info* info) {
   return FRBCH_OK;
 }
 
+extern "C" int frbch_reset(frbch_handle* h) {
+  if (!h) return FRBCH_E_ARG;
+  CHECK_DEV(h, dev_sync(h->stream), "sync");
+  h->pow_rows = 0;
+  h->rows_out = h->blocks_done = 0;
+  h->have_vdif = false;
+  h->carry.clear();
+  h->outq.clear();
+  h->outq_pos = 0;
+  h->skip_bytes = 0;
+  dev_free(h->d_frames); h->d_frames = nullptr;
+  dev_free(h->d_out); h->d_out = nullptr;
+  const bool off = h->pl.interval_rows == 0;
+  h->have_scale = off;
+  h->scale_frozen = off;
+  return set_identity_rescale(h);
+}
+
 extern "C" int frbch_get_rescale(frbch_handle* h, float* offset, float* scale) {
   if (!h || !offset || !scale) return FRBCH_E_ARG;
   if (!h->have_scale) return fail(h, FRBCH_E_STATE, "rescale not measured yet");

@@ -118,6 +118,8 @@ void frbch_close(frbch_handle* h);
 const char* frbch_last_error(frbch_handle* h);                 /* replaces: digifil's stderr  */
 const char* frbch_strerror(int code);
 int frbch_get_info(frbch_handle* h, frbch_info* info);
+/* forget stream + rescale state (as if freshly opened; buffers and tables are kept) */
+int frbch_reset(frbch_handle* h);
 
 /* ---- whole-file path: what `digifil ... -o <out> <hdr>` does (process_vdif.py:191) ---------
  * Reads cfg.datafile-style VDIF at `vdif_path`, honours -S/-T, writes SIGPROC header + samples to
