@@ -134,6 +134,7 @@ def main():
     c = ch.Channeliser(cfg)
     info = c.info
     frames, nfr = synth_frames_device(torch, dev, args.seconds, args.bw, args.nchan, if_index=rank)
+    torch.cuda.synchronize()   # the library runs on its own stream: inputs must be complete
     nblocks = (nfr * 8000) // info.block_payload_bytes
     rows = nblocks * info.rows_per_block
     out = torch.empty(rows * info.row_bytes, dtype=torch.uint8, device=dev)
