@@ -1,0 +1,142 @@
+"""Multi-IF orchestration: IF -> GPU/rank sharding and the host-side frequency concatenation.
+
+The reference runs one process per IF (base2fil.sh:60-66), LSB (odd) IFs then USB (even) IFs
+(:407-414), each writing a named FIFO, and joins them with sigproc ``splice`` whose argument list
+is built highest IF first (base2fil.sh:350,367,422).  IFs never exchange data, so on a multi-GPU
+node every rank owns whole IFs (IF i -> rank i mod world) and there is NO collective on the data
+path; the only exchange is this host-side concatenation of [t][chan] rows.
+"""
+from __future__ import annotations
+
+import os
+import struct
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import sigproc
+
+
+@dataclass
+class IfPlan:
+    index: int          # 1-based IF number as in <exp>_<st>_no0<scan>_IF<i>.vdif
+    sideband: str       # 'l' (odd IFs) or 'u' (even IFs)   base2fil.sh:266-268,407-414
+    freq_mhz: float     # value passed as -f: freqLSB_0 + (i-1)*bw  (base2fil.sh:54,65,254)
+
+
+def plan_ifs(nif: int, freq_lsb_0: float, bw: float):
+    """Frequency / sideband bookkeeping of run_process_vdif (base2fil.sh:30-67): within a sideband
+    the centre steps by 2*bw; the USB series starts at freqLSB_0 + bw."""
+    out = []
+    for i in range(1, nif + 1):
+        if i % 2 == 1:
+            out.append(IfPlan(i, "l", freq_lsb_0 + ((i - 1) // 2) * 2.0 * bw))
+        else:
+            out.append(IfPlan(i, "u", (freq_lsb_0 + bw) + ((i - 2) // 2) * 2.0 * bw))
+    return out
+
+
+def shard(nif: int, world: int, rank: int):
+    """IF numbers (1-based) owned by ``rank``: IF i -> rank (i-1) mod world."""
+    return [i for i in range(1, nif + 1) if (i - 1) % world == rank]
+
+
+def splice_order(nif: int):
+    """Order in which base2fil.sh hands the per-IF filterbanks to splice: highest IF first."""
+    return list(range(nif, 0, -1))
+
+
+def _put_str(s: str) -> bytes:
+    b = s.encode("ascii")
+    return struct.pack("<i", len(b)) + b
+
+
+def _header_bytes(h: dict) -> bytes:
+    out = _put_str("HEADER_START")
+    for key, val in h.items():
+        out += _put_str(key)
+        if isinstance(val, str):
+            out += _put_str(val)
+        elif isinstance(val, int):
+            out += struct.pack("<i", val)
+        else:
+            out += struct.pack("<d", float(val))
+    return out + _put_str("HEADER_END")
+
+
+def splice(inputs, out_path: str | None = None) -> bytes:
+    """Frequency-concatenate per-IF filterbanks given in DESCENDING frequency order (the order of
+    base2fil.sh's splice_list).  ``inputs``: paths or bytes.  Rows are cut to the shortest input.
+    Output: one SIGPROC file, nchans = sum, fch1 of the first input, [t][product][IF0 chans, IF1 ...]."""
+    fils = [sigproc.read_fil(x) for x in inputs]
+    first = fils[0].header
+    for f in fils[1:]:
+        for key in ("nbits", "nifs", "tsamp"):
+            if f.header[key] != first[key]:
+                raise ValueError(f"cannot splice: {key} differs ({f.header[key]} vs {first[key]})")
+        if abs(f.header["tstart"] - first["tstart"]) > 0.5 * first["tsamp"] / 86400.0:
+            raise ValueError("cannot splice: tstart differs")
+    nt = min(f.data.shape[0] for f in fils)
+    data = np.concatenate([f.data[:nt] for f in fils], axis=2)   # [t][nifs][sum chans]
+    hdr = dict(first)
+    hdr["nchans"] = int(data.shape[2])
+    nbits = first["nbits"]
+    if nbits == 2:
+        flat = data.reshape(-1, 4).astype(np.uint8)
+        body = (flat[:, 0] | (flat[:, 1] << 2) | (flat[:, 2] << 4) | (flat[:, 3] << 6)).astype(np.uint8).tobytes()
+    elif nbits == 8:
+        body = data.astype(np.uint8).tobytes()
+    elif nbits == 16:
+        body = data.astype("<u2").tobytes()
+    else:
+        body = data.astype("<f4").tobytes()
+    blob = _header_bytes(hdr) + body
+    if out_path:
+        with open(out_path, "wb") as f:
+            f.write(blob)
+    return blob
+
+
+def ifall_name(experiment: str, st: str, scanname: str, pol: int) -> str:
+    """Name of the spliced product (base2fil.sh:389)."""
+    return f"{experiment}_{st}_no0{scanname}_IFall_vdif_pol{pol}.fil"
+
+
+def process_scan(vdif_by_if: dict, *, freq_lsb_0: float, bw: float, nchan: int, nsec: float, start: float = 0.0,
+                 pol: int = 2, nbit: int = 8, tscrunch: int = 1, keepBP: bool = False, source: str = "unknown",
+                 ra: str = "00:00:00.0", dec: str = "00:00:00.0", telescope: str = "ONSALA85",
+                 out_dir: str, out_name: str = "IFall.fil", rank: int = 0, world: int = 1, local_device: int = 0,
+                 barrier=None, lib=None):
+    """Channelise this rank's IFs (one handle per IF on GPU ``local_device``) into
+    ``out_dir/<vdif basename>_pol<pol>.fil`` and, on rank 0 after ``barrier()``, splice all IFs.
+
+    ``vdif_by_if``: {IF number: path}.  No data-path collective: ranks only meet at the barrier.
+    Returns the spliced path on rank 0, else None."""
+    from . import channeliser as ch
+    from . import process_vdif as pv
+    nif = len(vdif_by_if)
+    plans = {p.index: p for p in plan_ifs(nif, freq_lsb_0, bw)}
+    mine = shard(nif, world, rank)
+    for i in mine:
+        p = plans[i]
+        path = vdif_by_if[i]
+        hdr = pv.make_hdr(source, p.freq_mhz, path, pol=pol, usb=(p.sideband == "u"), ra=ra, dec=dec, bw=bw,
+                          telescope=telescope)
+        fil = os.path.join(out_dir, os.path.basename(hdr).replace(".hdr", ".fil"))
+        cmd = pv.digifil_command(hdr, fil, start, nsec, nchan, pol, nbit, tscrunch, 1, 0.0, False, keepBP)
+        from . import digifil_args
+        cfg, _h, out = digifil_args.parse(cmd, lib=lib)
+        cfg.device = local_device
+        with ch.Channeliser(cfg, lib) as chan:
+            chan.run_file(path, out)
+    if barrier is not None:
+        barrier()
+    if rank != 0:
+        return None
+    ordered = []
+    for i in splice_order(nif):
+        base = os.path.basename(vdif_by_if[i]) + f"_pol{pol}.fil"
+        ordered.append(os.path.join(out_dir, base))
+    out_path = os.path.join(out_dir, out_name)
+    splice(ordered, out_path)
+    return out_path

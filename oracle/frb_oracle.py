@@ -220,7 +220,10 @@ def rescale_stats(p: np.ndarray):
 
 
 def rescale_apply(p: np.ndarray, offset: np.ndarray, scale: np.ndarray) -> np.ndarray:
-    return (p + offset[:, :, None]) * scale[:, :, None]
+    """out = (in + offset) * scale, evaluated in fp32 on fp32 data with fp32 offset/scale (the
+    stage works on float time series; only the statistics are accumulated in double)."""
+    p32 = p.astype(np.float32)
+    return (p32 + offset.astype(np.float32)[:, :, None]) * scale.astype(np.float32)[:, :, None]
 
 
 # --------------------------------------------------------------------------------------------
@@ -243,9 +246,11 @@ def digitise_values(x: np.ndarray, nbit: int) -> np.ndarray:
     mean, scale, vmax = digi_params(nbit)
     if nbit == -32:
         return x.astype(np.float32)
-    # the arithmetic is stated in fp32 (the stage is fp32 in the reference's engine)
-    v = x.astype(np.float32) * np.float32(scale) + np.float32(mean + 0.5)
-    v = np.clip(np.trunc(v), 0, vmax)
+    # the C expression `int(x * digi_scale + digi_mean + 0.5)` with float x, digi_scale, digi_mean:
+    # product and first sum are fp32, the 0.5 literal promotes the last sum to double (exact)
+    t = x.astype(np.float32) * np.float32(scale) + np.float32(mean)
+    v = np.clip(t.astype(np.float64) + 0.5, 0.0, float(vmax))   # clip first: no integer overflow
+    v = np.trunc(v)
     return v.astype(np.uint16 if nbit == 16 else np.uint8)
 
 

@@ -1,0 +1,174 @@
+"""CPU tests of the C-ABI host logic and of the generic kernels' index arithmetic, run through the
+TEST-ONLY host emulator build (tests/emu): same engine source, kernels executed by loops.
+The GPU parity tests proper are in test_gpu_parity.py."""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from frb_baseband_amd import channeliser as ch
+from frb_baseband_amd import sigproc, synth
+from oracle import frb_oracle as o
+from tests import parity_util as pu
+
+CASES = [
+    (16.0, 128, 0.03, {}),
+    (-16.0, 128, 0.03, {}),
+    (16.0, 64, 0.03, dict(pol=4)),
+    (-16.0, 32, 0.03, dict(pol=4, nbit=-32, tscr=4, freq_res=64)),
+    (16.0, 32, 0.03, dict(pol=0, nbit=2, tscr=2, freq_res=64)),
+    (16.0, 32, 0.03, dict(pol=3, nbit=16, freq_res=64, interval=0.0)),
+    (16.0, 32, 0.03, dict(pol=1, freq_res=64, interval=0.004, const=0)),
+    (16.0, 32, 0.03, dict(freq_res=64, interval=0.004, const=1, maxb=3)),
+    (16.0, 16, 0.02, dict(freq_res=16, tscr=16)),            # tscrunch == freq_res: one row per block
+    (32.0, 256, 0.03, dict(tscr=8)),                          # tscrunch > K2 sub-tile: LDS accumulators
+    (16.0, 32, 0.03, dict(freq_res=64, start=0.01)),          # -S inside the file
+]
+
+
+@pytest.mark.parametrize("bw,nchan,secs,kw", CASES)
+def test_fil_matches_oracle(emu_lib, bw, nchan, secs, kw):
+    pu.run_streaming_case(emu_lib, bw, nchan, secs, **kw)
+
+
+def test_ragged_pushes_equal_single_push(emu_lib):
+    raw = synth.make_vdif(0.03, bw_mhz=16.0, nchan=32)
+    cfg = pu.lib_cfg(emu_lib, 16.0, 32, 0.03, freq_res=64, interval=0.004, const=1)
+    with ch.Channeliser(cfg, emu_lib) as c:
+        whole = c.channelise_bytes(raw)
+    rng = np.random.default_rng(5)
+    with ch.Channeliser(cfg, emu_lib) as c:
+        pos, body = 0, bytearray()
+        while pos < raw.size:
+            n = int(rng.integers(1, 30000))
+            c.push(raw[pos:pos + n])
+            pos += n
+            body += c.pull()
+        c.flush()
+        body += c.pull()
+        ragged = c.sigproc_header() + bytes(body)
+    assert ragged == whole
+
+
+def test_total_seconds_limits_output(emu_lib):
+    raw = synth.make_vdif(0.03, bw_mhz=16.0, nchan=32)
+    for secs in (0.004, 0.0101):
+        ocfg = pu.oracle_cfg(16.0, 32, secs, freq_res=64)
+        ref = o.channelise(raw, ocfg)
+        with ch.Channeliser(pu.lib_cfg(emu_lib, 16.0, 32, secs, freq_res=64), emu_lib) as c:
+            got = c.channelise_bytes(raw)
+        pu.check_codes(ref, got, ocfg)
+
+
+def test_empty_and_short_inputs(emu_lib):
+    cfg = pu.lib_cfg(emu_lib, 16.0, 32, 1.0, freq_res=64)
+    with ch.Channeliser(cfg, emu_lib) as c:                  # nothing pushed
+        c.flush()
+        assert c.pull() == b""
+        with pytest.raises(ch.RunError):
+            c.sigproc_header()
+    raw = synth.make_vdif(1.0 / 16000, bw_mhz=16.0, nchan=32, payload_bytes=1000)   # 1 frame < one block
+    with ch.Channeliser(cfg, emu_lib) as c:
+        fil = c.channelise_bytes(raw)
+    f = sigproc.read_fil(fil)
+    assert f.data.shape[0] == 0 and f.header["nchans"] == 32
+
+
+def test_legacy_headers_and_other_payload(emu_lib):
+    for legacy, payload in ((1, 8000), (0, 1000)):
+        raw = synth.make_vdif(0.02, bw_mhz=16.0, nchan=32, legacy=legacy, payload_bytes=payload)
+        ocfg = pu.oracle_cfg(16.0, 32, 0.02, freq_res=64)
+        ref = o.channelise(raw, ocfg)
+        with ch.Channeliser(pu.lib_cfg(emu_lib, 16.0, 32, 0.02, freq_res=64), emu_lib) as c:
+            got = c.channelise_bytes(raw)
+            assert c.get_info().header_bytes == (16 if legacy else 32)
+        pu.check_codes(ref, got, ocfg)
+
+
+def test_rejects_unsupported_streams(emu_lib):
+    raw = synth.make_vdif(0.002, bw_mhz=16.0, nchan=32).copy()
+    raw[15] = (raw[15] & 0x83) | (7 << 2)                    # bits/sample-1 = 7 -> 8-bit samples
+    with ch.Channeliser(pu.lib_cfg(emu_lib, 16.0, 32, 1.0, freq_res=64), emu_lib) as c:
+        with pytest.raises(ch.RunError):
+            c.push(raw)
+    for bad in (dict(nchan=100), dict(tscrunch=3), dict(nbit_out=4), dict(pol_mode=7), dict(coherent=1),
+                dict(bw_mhz=0.0), dict(nchan=32, freq_res=64, tscrunch=128)):
+        with pytest.raises(ch.InputError):
+            ch.Channeliser(ch.new_config(emu_lib, **bad), emu_lib)
+
+
+def test_set_rescale_gives_reproducible_codes(emu_lib):
+    """given the same scale the digitised integers are reproducible (SURVEY 7 hard part 6)."""
+    raw = synth.make_vdif(0.03, bw_mhz=16.0, nchan=32)
+    cfg = pu.lib_cfg(emu_lib, 16.0, 32, 0.03, freq_res=64)
+    with ch.Channeliser(cfg, emu_lib) as c:
+        a = c.channelise_bytes(raw)
+        off, sc = c.get_rescale()
+    with ch.Channeliser(cfg, emu_lib) as c:
+        c.set_rescale(off, sc)                               # fused path from the first block on
+        b = c.channelise_bytes(raw)
+    assert a == b
+    ocfg = pu.oracle_cfg(16.0, 32, 0.03, freq_res=64)
+    ocfg.fixed_offset, ocfg.fixed_scale = off, sc
+    pu.check_codes(o.channelise(raw, ocfg), b, ocfg)
+
+
+def test_run_file_into_fifo(emu_lib, tmp_path):
+    """-o may be a pre-made FIFO (base2fil.sh:348-349): opened without O_EXCL, written sequentially,
+    never unlinked (INSTALL.md:32-35; process_vdif.py:146-149)."""
+    raw = synth.make_vdif(0.03, bw_mhz=16.0, nchan=32)
+    vd = tmp_path / "a_IF1.vdif"
+    raw.tofile(vd)
+    fifo = str(tmp_path / "a_IF1.vdif_pol2.fil")
+    os.mkfifo(fifo)
+    got = {}
+
+    def reader():
+        with open(fifo, "rb") as f:
+            got["data"] = f.read()
+    th = threading.Thread(target=reader)
+    th.start()
+    with ch.Channeliser(pu.lib_cfg(emu_lib, 16.0, 32, 0.03, freq_res=64), emu_lib) as c:
+        c.run_file(str(vd), fifo)
+    th.join(timeout=30)
+    assert os.path.exists(fifo)
+    ocfg = pu.oracle_cfg(16.0, 32, 0.03, freq_res=64)
+    pu.check_codes(o.channelise(raw, ocfg), got["data"], ocfg)
+    # regular file target: truncated and rewritten
+    out = str(tmp_path / "o.fil")
+    open(out, "wb").write(b"x" * 10_000_000)
+    with ch.Channeliser(pu.lib_cfg(emu_lib, 16.0, 32, 0.03, freq_res=64), emu_lib) as c:
+        c.run_file(str(vd), out)
+    assert open(out, "rb").read() == got["data"]
+    with ch.Channeliser(pu.lib_cfg(emu_lib, 16.0, 32, 0.03, freq_res=64), emu_lib) as c:
+        with pytest.raises(ch.RunError):
+            c.run_file(str(tmp_path / "missing.vdif"), out)
+
+
+def test_device_entry_points_and_power_tap(emu_lib):
+    """frbch_process_device / flush_device / power_device semantics (emulator: host pointers)."""
+    bw, nchan, r = 16.0, 32, 64
+    raw = synth.make_vdif(0.02, bw_mhz=bw, nchan=nchan)
+    with ch.Channeliser(pu.lib_cfg(emu_lib, bw, nchan, 0.02, freq_res=r), emu_lib) as c:
+        info = c.info
+        nfr = raw.size // 8032
+        nblocks = (nfr * 8000) // info.block_payload_bytes
+        rows = nblocks * info.rows_per_block
+        out = np.zeros(rows * info.row_bytes, np.uint8)
+        r1 = c.process_device(raw.ctypes.data, nfr, 8032, 32, 0, nblocks, out.ctypes.data, out.size)
+        assert r1 == 0                                       # interval still being measured
+        r2 = c.flush_device(out.ctypes.data, out.size)
+        assert r2 == rows
+        with pytest.raises(ch.InputError):
+            c.process_device(raw.ctypes.data, nfr, 8032, 32, 0, nblocks + 1, out.ctypes.data, out.size)
+        c.reset()
+        pw = np.zeros(rows * info.nif * nchan, np.float32)
+        c.power_device(raw.ctypes.data, nfr, 8032, 32, 0, nblocks, pw.ctypes.data, pw.nbytes)
+    ocfg = pu.oracle_cfg(bw, nchan, 0.02, freq_res=r)
+    ref = sigproc.read_fil(o.channelise(raw, ocfg))
+    assert np.count_nonzero(out.reshape(ref.data.shape) != ref.data) <= 2
+    want = ocfg.result["power"][:, ::-1, :].transpose(2, 0, 1).reshape(-1)   # USB: flipped
+    scale = ocfg.result["power"].mean()
+    assert np.abs(pw - want).max() <= pu.POWER_RTOL * scale

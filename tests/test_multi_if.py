@@ -1,0 +1,72 @@
+"""IF sharding over ranks + host-side frequency concatenation (replaces splice, base2fil.sh:422).
+world_size-2 gloo run on CPU; the per-IF compute goes through the TEST-ONLY emulator library."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from frb_baseband_amd import multi_if, sigproc, synth
+from oracle import frb_oracle as o
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_frequency_plan_matches_base2fil():
+    # base2fil.sh:54,65,254: LSB series from freqLSB_0 step 2bw; USB series from freqLSB_0+bw
+    plans = multi_if.plan_ifs(4, 1340.49, 32.0)
+    assert [(p.index, p.sideband) for p in plans] == [(1, "l"), (2, "u"), (3, "l"), (4, "u")]
+    assert [p.freq_mhz for p in plans] == pytest.approx([1340.49, 1372.49, 1404.49, 1436.49])
+    assert multi_if.splice_order(4) == [4, 3, 2, 1]
+    assert multi_if.shard(16, 8, 0) == [1, 9] and multi_if.shard(16, 8, 7) == [8, 16]
+    assert sorted(sum((multi_if.shard(5, 2, r) for r in range(2)), [])) == [1, 2, 3, 4, 5]
+    assert multi_if.ifall_name("pr001a", "ef", "001", 2) == "pr001a_ef_no0001_IFall_vdif_pol2.fil"
+
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from frb_baseband_amd import multi_if, _lib
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+lib = _lib.load(os.path.join(sys.argv[1], "tests", "emu", "libfrbch_emu.so"))
+d = sys.argv[2]
+vd = {i: os.path.join(d, f"x_ef_no0001_IF{i}.vdif") for i in (1, 2, 3, 4)}
+out = multi_if.process_scan(vd, freq_lsb_0=1340.0, bw=16.0, nchan=32, nsec=0.02, out_dir=d, rank=rank, world=world,
+                            barrier=dist.barrier, lib=lib, ra="01:00:00.0", dec="02:00:00.0")
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_scan_equals_oracle_splice(emu_lib, tmp_path):
+    d = str(tmp_path)
+    raws = {}
+    for i in (1, 2, 3, 4):
+        raws[i] = synth.make_vdif(0.02, bw_mhz=16.0, nchan=32, if_index=i)
+        raws[i].tofile(os.path.join(d, f"x_ef_no0001_IF{i}.vdif"))
+    script = os.path.join(d, "worker.py")
+    open(script, "w").write(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, script, ROOT, d], env=dict(env, RANK=str(r))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    got = sigproc.read_fil(os.path.join(d, "IFall.fil"))
+    # oracle: channelise every IF with the base2fil frequency plan, concatenate highest IF first
+    parts = []
+    for i in (4, 3, 2, 1):
+        plan = multi_if.plan_ifs(4, 1340.0, 16.0)[i - 1]
+        bw = 16.0 if plan.sideband == "u" else -16.0
+        cfg = o.Config(bw_mhz=bw, freq_mhz=plan.freq_mhz, nchan=32, total_s=0.02, source="unknown")
+        parts.append(sigproc.read_fil(o.channelise(raws[i], cfg)))
+    want = np.concatenate([p.data for p in parts], axis=2)
+    assert got.data.shape == want.shape == (parts[0].data.shape[0], 1, 128)
+    assert np.count_nonzero(got.data != want) <= 2e-5 * want.size      # +-1 at rounding ties only
+    assert np.abs(got.data.astype(int) - want.astype(int)).max() <= 1
+    assert got.header["nchans"] == 128
+    assert got.header["fch1"] == pytest.approx(parts[0].header["fch1"])
+    fch = [p.header["fch1"] for p in parts]
+    assert fch == sorted(fch, reverse=True)                 # descending frequency across IFs
+    assert fch[0] - fch[1] == pytest.approx(16.0)
