@@ -25,7 +25,7 @@ class FrbchConfig(C.Structure):
         ("nbit_out", C.c_int32), ("pol_mode", C.c_int32), ("rescale_constant", C.c_uint32),
         ("rescale_interval_s", C.c_double), ("dm", C.c_double),
         ("coherent", C.c_uint32), ("device", C.c_int32),
-        ("max_blocks_per_launch", C.c_uint32), ("reserved0", C.c_uint32),
+        ("max_blocks_per_launch", C.c_uint32), ("flags", C.c_uint32),
         ("telescope", C.c_char * 64), ("source", C.c_char * 64),
         ("ra", C.c_char * 32), ("dec", C.c_char * 32), ("datafile", C.c_char * 512),
     ]

@@ -23,6 +23,9 @@
 #include "frbch_kparams.h"
 
 #include "kernels_generic.inc"
+#ifndef FRBCH_NO_FAST
+#include "kernels_fast.inc"
+#endif
 
 using namespace frbch;
 
@@ -50,6 +53,7 @@ struct frbch_handle {
 
   // constant tables
   cf *tw_r = nullptr, *tw_c2 = nullptr, *tw_nhi = nullptr, *tw_nlo = nullptr;
+  cf *ftw1_r = nullptr, *ftw2_r = nullptr, *ftw1_c = nullptr, *ftw2_c = nullptr, *td1 = nullptr, *td2 = nullptr;
   // per-launch work buffers
   cf *spill = nullptr, *s_dc = nullptr, *p0 = nullptr;
   // rescale state
@@ -163,6 +167,12 @@ KParams base_params(const frbch_handle* h) {
   p.tw_c2 = h->tw_c2;
   p.tw_nhi = h->tw_nhi;
   p.tw_nlo = h->tw_nlo;
+  p.ftw1_r = h->ftw1_r;
+  p.ftw2_r = h->ftw2_r;
+  p.ftw1_c = h->ftw1_c;
+  p.ftw2_c = h->ftw2_c;
+  p.td1 = h->td1;
+  p.td2 = h->td2;
   p.offset = h->offset;
   p.scale = h->scale;
   p.lut[0] = -3.3359f;
@@ -175,6 +185,124 @@ KParams base_params(const frbch_handle* h) {
   return p;
 }
 
+#ifndef FRBCH_NO_FAST
+template <int LOG2M>
+void launch_k1_fast_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
+  hipLaunchKernelGGL(fast::frbch_k1_fast<LOG2M>, dim3(pl.c2 / pl.g, nb), dim3(1024), pl.k1_fast_lds, s, p);
+}
+template <int LOG2M>
+void launch_k2_fast_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
+  const int tps = 16 << LOG2M;
+  if (pl.fast_k2_nt == 1024)
+    hipLaunchKernelGGL((fast::frbch_k2_fast<LOG2M, 1024>), dim3(pl.r / (1024 / tps), nb), dim3(1024), pl.k2_fast_lds, s, p);
+  else
+    hipLaunchKernelGGL((fast::frbch_k2_fast<LOG2M, 512>), dim3(pl.r / (512 / tps), nb), dim3(512), pl.k2_fast_lds, s, p);
+}
+bool launch_k1_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
+  const Plan& pl = h->pl;
+  if (!pl.fast_k1_log2m) return false;
+  const uint32_t rb = (uint32_t)pl.g / 2;   // input bytes per row piece: alignment of every piece
+  if (p.payload_off % rb || p.payload_bytes % rb || p.header_bytes % rb || p.frame_bytes % rb ||
+      ((uintptr_t)p.frames % 16))
+    return false;
+  switch (pl.fast_k1_log2m) {
+    case 1: launch_k1_fast_t<1>(pl, p, nb, s); break;
+    case 2: launch_k1_fast_t<2>(pl, p, nb, s); break;
+    case 3: launch_k1_fast_t<3>(pl, p, nb, s); break;
+    case 4: launch_k1_fast_t<4>(pl, p, nb, s); break;
+    default: return false;
+  }
+  return true;
+}
+bool launch_k2_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
+  const Plan& pl = h->pl;
+  switch (pl.fast_k2_log2m) {
+    case 1: launch_k2_fast_t<1>(pl, p, nb, s); break;
+    case 2: launch_k2_fast_t<2>(pl, p, nb, s); break;
+    case 3: launch_k2_fast_t<3>(pl, p, nb, s); break;
+    case 4: launch_k2_fast_t<4>(pl, p, nb, s); break;
+    default: return false;
+  }
+  return true;
+}
+template <class K>
+int allow_lds(frbch_handle* h, K kern, size_t bytes) {
+  CHECK_DEV(h, dev_allow_lds(kern, bytes), "LDS size (fast kernel)");
+  return FRBCH_OK;
+}
+int upload_cf(frbch_handle* h, cf** dst, const std::vector<float>& xy) {
+  CHECK_DEV(h, dev_malloc((void**)dst, xy.size() * sizeof(float)), "hipMalloc(fast tables)");
+  CHECK_DEV(h, dev_h2d(*dst, xy.data(), xy.size() * sizeof(float), h->stream), "upload fast tables");
+  CHECK_DEV(h, dev_sync(h->stream), "sync");
+  return FRBCH_OK;
+}
+void fft_tables(int len, std::vector<float>* tw1, std::vector<float>* tw2) {
+  const int tps = len / 16, m = len / 256;
+  tw1->resize(2 * (size_t)len);
+  for (int ka = 0; ka < 16; ++ka)
+    for (int q = 0; q < tps; ++q) {
+      const double a = -2.0 * M_PI * (double)(((uint64_t)q * ka) % len) / len;
+      (*tw1)[2 * ((size_t)ka * tps + q)] = (float)cos(a);
+      (*tw1)[2 * ((size_t)ka * tps + q) + 1] = (float)sin(a);
+    }
+  tw2->resize(2 * (size_t)m * 16);
+  for (int kb = 0; kb < m; ++kb)
+    for (int c = 0; c < 16; ++c) {
+      const double a = -2.0 * M_PI * (double)((c * kb) % tps) / tps;
+      (*tw2)[2 * (kb * 16 + c)] = (float)cos(a);
+      (*tw2)[2 * (kb * 16 + c) + 1] = (float)sin(a);
+    }
+}
+int setup_fast(frbch_handle* h) {
+  const Plan& pl = h->pl;
+  int rc;
+  std::vector<float> t1, t2;
+  if (pl.fast_k1_log2m) {
+    fft_tables(pl.r, &t1, &t2);
+    if ((rc = upload_cf(h, &h->ftw1_r, t1)) || (rc = upload_cf(h, &h->ftw2_r, t2))) return rc;
+    const int tps = pl.r / 16;
+    std::vector<float> d1(2 * (size_t)pl.c2 * 16), d2(2 * (size_t)pl.c2 * tps);
+    for (int n1 = 0; n1 < pl.c2; ++n1) {
+      for (int kc = 0; kc < 16; ++kc) {
+        const double a = -2.0 * M_PI * (double)((uint64_t)n1 * kc) / (16.0 * pl.c2);
+        d1[2 * ((size_t)n1 * 16 + kc)] = (float)cos(a);
+        d1[2 * ((size_t)n1 * 16 + kc) + 1] = (float)sin(a);
+      }
+      for (int k0 = 0; k0 < tps; ++k0) {
+        const double a = -2.0 * M_PI * (double)((uint64_t)n1 * k0) / (double)pl.n;
+        d2[2 * ((size_t)n1 * tps + k0)] = (float)cos(a);
+        d2[2 * ((size_t)n1 * tps + k0) + 1] = (float)sin(a);
+      }
+    }
+    if ((rc = upload_cf(h, &h->td1, d1)) || (rc = upload_cf(h, &h->td2, d2))) return rc;
+    switch (pl.fast_k1_log2m) {
+      case 1: rc = allow_lds(h, fast::frbch_k1_fast<1>, pl.k1_fast_lds); break;
+      case 2: rc = allow_lds(h, fast::frbch_k1_fast<2>, pl.k1_fast_lds); break;
+      case 3: rc = allow_lds(h, fast::frbch_k1_fast<3>, pl.k1_fast_lds); break;
+      default: rc = allow_lds(h, fast::frbch_k1_fast<4>, pl.k1_fast_lds); break;
+    }
+    if (rc) return rc;
+  }
+  if (pl.fast_k2_log2m) {
+    fft_tables(pl.c2, &t1, &t2);
+    if ((rc = upload_cf(h, &h->ftw1_c, t1)) || (rc = upload_cf(h, &h->ftw2_c, t2))) return rc;
+    const bool big = pl.fast_k2_nt == 1024;
+    switch (pl.fast_k2_log2m) {
+      case 1: rc = big ? allow_lds(h, fast::frbch_k2_fast<1, 1024>, pl.k2_fast_lds) : allow_lds(h, fast::frbch_k2_fast<1, 512>, pl.k2_fast_lds); break;
+      case 2: rc = big ? allow_lds(h, fast::frbch_k2_fast<2, 1024>, pl.k2_fast_lds) : allow_lds(h, fast::frbch_k2_fast<2, 512>, pl.k2_fast_lds); break;
+      case 3: rc = big ? allow_lds(h, fast::frbch_k2_fast<3, 1024>, pl.k2_fast_lds) : allow_lds(h, fast::frbch_k2_fast<3, 512>, pl.k2_fast_lds); break;
+      default: rc = big ? allow_lds(h, fast::frbch_k2_fast<4, 1024>, pl.k2_fast_lds) : allow_lds(h, fast::frbch_k2_fast<4, 512>, pl.k2_fast_lds); break;
+    }
+    if (rc) return rc;
+  }
+  return FRBCH_OK;
+}
+#else
+bool launch_k1_fast(frbch_handle*, KParams&, uint32_t, dev_stream_t) { return false; }
+bool launch_k2_fast(frbch_handle*, KParams&, uint32_t, dev_stream_t) { return false; }
+int setup_fast(frbch_handle*) { return FRBCH_OK; }
+#endif
+
 // K1 + Kc over nb blocks: frames -> spill, P0
 int launch_front(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   const Plan& pl = h->pl;
@@ -182,7 +310,7 @@ int launch_front(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
     const double bytes = (double)nb * ((double)pl.block_payload_bytes * p.frame_bytes / p.payload_bytes +
                                        (double)pl.n * 8.0 + (double)pl.c2 * 8.0);
     ProfScope ps(h, s, KID_K1, bytes);
-    DEV_LAUNCH(frbch_k1_branch, pl.c2 / pl.g, nb, pl.nthreads, pl.k1_lds, s, p);
+    if (!launch_k1_fast(h, p, nb, s)) DEV_LAUNCH(frbch_k1_branch, pl.c2 / pl.g, nb, pl.nthreads, pl.k1_lds, s, p);
   }
   {
     ProfScope ps(h, s, KID_KC, (double)nb * pl.c2 * 16.0);
@@ -198,7 +326,7 @@ int launch_back(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   const double out_b = p.out_mode == FRBCH_OUT_FLOAT_POWER ? (double)pl.ncol * 4.0 : (double)pl.row_bytes;
   const double bytes = (double)nb * ((double)pl.n * 8.0 + (double)pl.rows_per_block * out_b);
   ProfScope ps(h, s, KID_K2, bytes);
-  DEV_LAUNCH(frbch_k2_chan, pl.r / tile_t, nb, pl.nthreads, pl.k2_lds, s, p);
+  if (!launch_k2_fast(h, p, nb, s)) DEV_LAUNCH(frbch_k2_chan, pl.r / tile_t, nb, pl.nthreads, pl.k2_lds, s, p);
   CHECK_DEV(h, dev_check_launch(), "launch K2");
   return FRBCH_OK;
 }
@@ -393,6 +521,7 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
   const uint64_t nlo = 1ull << pl.log2_nlo, nhi = pl.n >> pl.log2_nlo;
   if ((rc = upload_table(h, &h->tw_nlo, pl.n, nlo, 1))) return rc;
   if ((rc = upload_table(h, &h->tw_nhi, pl.n, std::max<uint64_t>(1, nhi), nlo))) return rc;
+  if ((rc = setup_fast(h))) return rc;
 
   CHECK_DEV(h, dev_malloc((void**)&h->spill, (size_t)pl.maxb * pl.n * sizeof(cf)), "hipMalloc(spill)");
   CHECK_DEV(h, dev_malloc((void**)&h->s_dc, (size_t)pl.maxb * pl.c2 * sizeof(cf)), "hipMalloc(s_dc)");
@@ -412,6 +541,7 @@ extern "C" void frbch_close(frbch_handle* h) {
   if (h->stream) (void)dev_sync(h->stream);
   drain_events(h);
   dev_free(h->tw_r); dev_free(h->tw_c2); dev_free(h->tw_nhi); dev_free(h->tw_nlo);
+  dev_free(h->ftw1_r); dev_free(h->ftw2_r); dev_free(h->ftw1_c); dev_free(h->ftw2_c); dev_free(h->td1); dev_free(h->td2);
   dev_free(h->spill); dev_free(h->s_dc); dev_free(h->p0);
   dev_free(h->offset); dev_free(h->scale); dev_free(h->powbuf); dev_free(h->partial);
   dev_free(h->d_frames); dev_free(h->d_out);

@@ -147,6 +147,33 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit) {
     default: pl->digi_mean = 0.0f; pl->digi_scale = 1.0f; pl->digi_max = 0.0f; break;
   }
 
+  // fast path (kernels_fast.inc): lengths 512..4096 = 256*M, 16 points per thread
+  pl->fast_k1_log2m = pl->fast_k2_log2m = 0;
+  pl->fast_k2_nt = (cfg.flags & 4u) ? 1024 : 512;
+  pl->k1_fast_lds = pl->k2_fast_lds = 0;
+  if (!(cfg.flags & 1u) && r >= 512 && r <= 4096) {
+    const int m = (int)r / 256, gfast = 64 / m;
+    const size_t seq = (size_t)r + r / 8 + 8;
+    const size_t lds = (size_t)gfast * seq * 8 + (size_t)r * (gfast / 2);
+    const size_t generic_lds = (size_t)gfast * seq1;   // fallback for unaligned calls keeps the layout
+    if (gfast <= pl->c2 && lds <= lds_limit && generic_lds <= lds_limit) {
+      pl->fast_k1_log2m = ilog2(m);
+      pl->g = gfast;
+      pl->k1_lds = generic_lds;
+      pl->k1_fast_lds = lds;
+    }
+  }
+  if (!(cfg.flags & 2u) && pl->c2 >= 512 && pl->c2 <= 4096 && pl->g >= 2) {
+    const int m = pl->c2 / 256;
+    const int tt = pl->fast_k2_nt / (16 * m);
+    const size_t seq = (size_t)pl->c2 + pl->c2 / 8 + 8;
+    const size_t lds = (size_t)tt * seq * 8;
+    if (tt >= 1 && pl->tscr <= tt && tt <= (int)r && (size_t)tt * pl->ncol * 4 <= lds && lds <= lds_limit) {
+      pl->fast_k2_log2m = ilog2(m);
+      pl->k2_fast_lds = lds;
+    }
+  }
+
   uint32_t maxb = cfg.max_blocks_per_launch;
   if (!maxb) {
     const uint64_t spill_per_block = pl->n * 8;

@@ -34,6 +34,10 @@ struct Plan {
   uint64_t interval_rows;     // rescale interval in output rows; 0 = disabled
   size_t k1_lds, k2_lds, kc_lds;
   uint32_t maxb;              // blocks per launch
+  int fast_k1_log2m;          // 0 = generic K1, else log2(M) with R = 256*M
+  int fast_k2_log2m;          // 0 = generic K2, else log2(M) with 2C = 256*M
+  int fast_k2_nt;             // threads per K2 workgroup (512 / 1024)
+  size_t k1_fast_lds, k2_fast_lds;
   double rate_in;             // real samples / s / pol
   double rate_out;            // output rows / s
   double tsamp_s;

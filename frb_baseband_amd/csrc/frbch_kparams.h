@@ -33,11 +33,18 @@ struct KParams {
   // ---- work buffers -------------------------------------------------------------------------
   cf* spill;                // [nblk][2C/g][R][g]   delayed branch series w[n1][t]
   cf* s_dc;                 // [nblk][2C]           S[n1] = sum_n2 p[n1 + 2C n2]
-  cf* p0;                   // [nblk][2C]           P[k'R] = FFT_2C(S)
+  cf* p0;                   // [nblk][2C]           dP[k'] = P[(k'+1)R] - P[k'R], P[k'R] = FFT_2C(S)
   const cf* tw_r;           // exp(-2 pi i k / R),  k < R/2
   const cf* tw_c2;          // exp(-2 pi i k / 2C), k < C
   const cf* tw_nhi;         // exp(-2 pi i (h << log2_nlo) / N)
   const cf* tw_nlo;         // exp(-2 pi i l / N)
+  // fast-path tables (kernels_fast.inc): L = 256*M, TPS = 16*M
+  const cf* ftw1_r;         // [16][R/16]   exp(-2 pi i p ka / R)
+  const cf* ftw2_r;         // [M][16]      exp(-2 pi i c kb / (R/16))
+  const cf* ftw1_c;         // same for the across-branch length 2C
+  const cf* ftw2_c;
+  const cf* td1;            // [2C][16]     exp(-2 pi i n1 kc / (16*2C))      (delay, coarse part)
+  const cf* td2;            // [2C][R/16]   exp(-2 pi i n1 k0 / N)            (delay, fine part)
   const float* offset;      // [nif][C], input channel order k
   const float* scale;       // [nif][C]
   float* power_out;         // [row][nif][C] float32, output channel order

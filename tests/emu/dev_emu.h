@@ -12,6 +12,7 @@
 #include <vector>
 
 #define FRBCH_BACKEND_NAME "host-emulator(test-only)"
+#define FRBCH_NO_FAST 1   /* the register-level gfx950 kernels are HIP only */
 #define DEVFN static
 #define KERNEL(name, PT) static void name(PT p, int bx, int by, int nthr, unsigned char* smem)
 #define K_PROLOGUE ((void)0)

@@ -28,10 +28,10 @@ def oracle_cfg(bw, nchan, secs, pol=2, nbit=8, tscr=1, interval=10.0, const=1, f
                     freq_res=freq_res, source="unknown", telescope="ONSALA85")
 
 
-def lib_cfg(lib, bw, nchan, secs, pol=2, nbit=8, tscr=1, interval=10.0, const=1, freq_res=0, start=0.0, maxb=0):
+def lib_cfg(lib, bw, nchan, secs, pol=2, nbit=8, tscr=1, interval=10.0, const=1, freq_res=0, start=0.0, maxb=0, flags=0):
     return ch.new_config(lib, bw_mhz=bw, nchan=nchan, total_s=secs, start_s=start, pol_mode=pol,
                          nbit_out=nbit, tscrunch=tscr, rescale_interval_s=interval,
-                         rescale_constant=const, freq_res=freq_res, max_blocks_per_launch=maxb)
+                         rescale_constant=const, freq_res=freq_res, max_blocks_per_launch=maxb, flags=flags)
 
 
 def expected_boundary_distance(ocfg):
@@ -67,7 +67,7 @@ def check_codes(ref_bytes, got_bytes, ocfg):
 def run_streaming_case(lib, bw, nchan, secs, **kw):
     """oracle .fil vs library .fil through push/flush/pull; returns mismatch count"""
     raw = synth.make_vdif(secs + kw.get("start", 0.0), bw_mhz=abs(bw), nchan=nchan)
-    ocfg = oracle_cfg(bw, nchan, secs, **{k: v for k, v in kw.items() if k != "maxb"})
+    ocfg = oracle_cfg(bw, nchan, secs, **{k: v for k, v in kw.items() if k not in ("maxb", "flags")})
     ref = o.channelise(raw, ocfg)
     cfg = lib_cfg(lib, bw, nchan, secs, **kw)
     with ch.Channeliser(cfg, lib) as c:

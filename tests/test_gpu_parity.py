@@ -16,10 +16,50 @@ CASES = [
     (16.0, 32, 0.05, dict(pol=3, nbit=16, freq_res=64, interval=0.0)),   # -I0 (keepBP)
     (16.0, 32, 0.05, dict(pol=1, freq_res=64, interval=0.004, const=0)),  # no -c: per-interval rescale
     (16.0, 32, 0.05, dict(freq_res=64, interval=0.004, const=1, maxb=3)),
-    (32.0, 1024, 0.14, {}),                                  # BASELINE config 2 shape, 2 blocks
+    (32.0, 1024, 0.14, {}),                                  # BASELINE config 2 shape, 2 blocks (fast K1+K2, M=8)
+    (32.0, 1024, 0.14, dict(flags=3)),                       # same through the generic kernels
+    (32.0, 1024, 0.14, dict(flags=1)),                       # generic K1 + fast K2
+    (32.0, 1024, 0.14, dict(flags=2)),                       # fast K1 + generic K2
+    (32.0, 1024, 0.14, dict(flags=4)),                       # 1024-thread K2
+    (-32.0, 1024, 0.14, dict(pol=4, tscr=2)),                # BASELINE config 3 shape (-d4), LSB, -t 2
+    (-32.0, 1024, 0.14, dict(pol=4, tscr=4, nbit=-32)),
+    (32.0, 1024, 0.14, dict(pol=0, nbit=2, tscr=4)),
+    (32.0, 1024, 0.14, dict(pol=1, nbit=16, interval=0.0)),
+    (32.0, 1024, 0.14, dict(pol=3, interval=0.05, const=0)),
+    (32.0, 1024, 0.2, dict(start=0.05, maxb=2)),             # -S, odd batching
+    (16.0, 256, 0.04, {}),                                   # M = 2  (R = 2C = 512)
+    (16.0, 256, 0.04, dict(pol=4, tscr=8)),
+    (-16.0, 512, 0.08, dict(tscr=2)),                        # M = 4  (R = 2C = 1024)
+    (64.0, 2048, 0.3, dict(tscr=2)),                         # M = 16 (R = 2C = 4096), config-5 channel count
+    (64.0, 2048, 0.3, dict(pol=4, tscr=4)),                  # tscrunch > fast K2 tile: generic K2 + fast K1
+    (32.0, 512, 0.1, dict(freq_res=2048)),                   # R != 2C: fast K1 (M=8) + fast K2 (M=4)
 ]
 
 
 @pytest.mark.parametrize("bw,nchan,secs,kw", CASES)
 def test_fil_matches_oracle(hip_lib, bw, nchan, secs, kw):
     pu.run_streaming_case(hip_lib, bw, nchan, secs, **kw)
+
+
+def test_power_tap_matches_oracle(hip_lib):
+    """float32 power of the fused unpack->FFT->detect stream vs the fp64 oracle (tolerance stated in parity_util)."""
+    import torch
+    from frb_baseband_amd import channeliser as ch, synth
+    from oracle import frb_oracle as o
+    bw, nchan = 32.0, 1024
+    raw = synth.make_vdif(0.14, bw_mhz=bw, nchan=nchan)
+    ocfg = pu.oracle_cfg(bw, nchan, 0.14, pol=4)
+    o.channelise(raw, ocfg)
+    want = ocfg.result["power"][:, ::-1, :].transpose(2, 0, 1)          # [t][prod][chan], USB flipped
+    d_raw = torch.from_numpy(raw).cuda()
+    with ch.Channeliser(pu.lib_cfg(hip_lib, bw, nchan, 0.14, pol=4), hip_lib) as c:
+        info = c.info
+        nfr = raw.size // 8032
+        nblocks = (nfr * 8000) // info.block_payload_bytes
+        pw = torch.empty(nblocks * info.rows_per_block * 4 * nchan, dtype=torch.float32, device="cuda")
+        c.power_device(d_raw.data_ptr(), nfr, 8032, 32, 0, nblocks, pw.data_ptr(), pw.numel() * 4)
+        torch.cuda.synchronize()
+    got = pw.cpu().numpy().reshape(want.shape).astype(np.float64)
+    scale = ocfg.result["power"][0].mean()
+    err = np.abs(got - want).max() / scale
+    assert err <= pu.POWER_RTOL, err
