@@ -43,23 +43,23 @@ def test_fil_matches_oracle(hip_lib, bw, nchan, secs, kw):
 
 def test_power_tap_matches_oracle(hip_lib):
     """float32 power of the fused unpack->FFT->detect stream vs the fp64 oracle (tolerance stated in parity_util)."""
-    import torch
     from frb_baseband_amd import channeliser as ch, synth
+    from tests.hipmem import DeviceBuffer
     from oracle import frb_oracle as o
     bw, nchan = 32.0, 1024
     raw = synth.make_vdif(0.14, bw_mhz=bw, nchan=nchan)
     ocfg = pu.oracle_cfg(bw, nchan, 0.14, pol=4)
     o.channelise(raw, ocfg)
     want = ocfg.result["power"][:, ::-1, :].transpose(2, 0, 1)          # [t][prod][chan], USB flipped
-    d_raw = torch.from_numpy(raw).cuda()
+    d_raw = DeviceBuffer.from_numpy(raw)
     with ch.Channeliser(pu.lib_cfg(hip_lib, bw, nchan, 0.14, pol=4), hip_lib) as c:
         info = c.info
         nfr = raw.size // 8032
         nblocks = (nfr * 8000) // info.block_payload_bytes
-        pw = torch.empty(nblocks * info.rows_per_block * 4 * nchan, dtype=torch.float32, device="cuda")
-        c.power_device(d_raw.data_ptr(), nfr, 8032, 32, 0, nblocks, pw.data_ptr(), pw.numel() * 4)
-        torch.cuda.synchronize()
-    got = pw.cpu().numpy().reshape(want.shape).astype(np.float64)
+        pw = DeviceBuffer(nblocks * info.rows_per_block * 4 * nchan * 4)
+        c.power_device(d_raw.ptr.value, nfr, 8032, 32, 0, nblocks, pw.ptr.value, pw.nbytes)
+        got = pw.to_numpy(np.float32).reshape(want.shape).astype(np.float64)
     scale = ocfg.result["power"][0].mean()
     err = np.abs(got - want).max() / scale
+    print("max |P - P_oracle| / mean(P) =", err)
     assert err <= pu.POWER_RTOL, err
