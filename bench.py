@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--maxb", type=int, default=0, help="filterbank blocks per kernel launch (0 = library default)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--flags", type=int, default=0, help="debug flags of frbch_config (see include/frbch.h)")
     args = ap.parse_args()
 
     import torch
@@ -130,7 +131,7 @@ def main():
     from frb_baseband_amd import channeliser as ch
     cfg = ch.new_config(bw_mhz=args.bw, nchan=args.nchan, pol_mode=args.pol, nbit_out=8, tscrunch=1,
                         rescale_constant=1, rescale_interval_s=10.0, total_s=args.seconds, device=local_rank,
-                        max_blocks_per_launch=args.maxb)
+                        max_blocks_per_launch=args.maxb, flags=args.flags)
     c = ch.Channeliser(cfg)
     info = c.info
     frames, nfr = synth_frames_device(torch, dev, args.seconds, args.bw, args.nchan, if_index=rank)

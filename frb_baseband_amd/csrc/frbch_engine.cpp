@@ -182,6 +182,7 @@ KParams base_params(const frbch_handle* h) {
   p.digi_mean = pl.digi_mean;
   p.digi_scale = pl.digi_scale;
   p.digi_max = pl.digi_max;
+  p.dbg = h->cfg.flags >> 8;
   return p;
 }
 
@@ -189,6 +190,23 @@ KParams base_params(const frbch_handle* h) {
 template <int LOG2M>
 void launch_k1_fast_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
   hipLaunchKernelGGL(fast::frbch_k1_fast<LOG2M>, dim3(pl.c2 / pl.g, nb), dim3(1024), pl.k1_fast_lds, s, p);
+}
+template <int LOG2M>
+void launch_k1_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
+  hipLaunchKernelGGL(fast::frbch_k1_wave<LOG2M>, dim3(pl.c2 / pl.g, nb), dim3(512), pl.k1_fast_lds, s, p);
+}
+template <int LOG2M>
+void launch_k2_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
+  const int tps = 16 << LOG2M;
+  const int tt = 4 * (tps < 64 ? 64 / tps : 1);
+  hipLaunchKernelGGL(fast::frbch_k2_wave<LOG2M>, dim3(pl.r / tt, nb), dim3(256), pl.k2_fast_lds, s, p);
+}
+void set_fastdiv(KParams& p) {
+  const uint32_t d = p.payload_bytes;
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;
+  p.div_magic = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+  p.div_shift = l ? l - 1 : 0;
 }
 template <int LOG2M>
 void launch_k2_fast_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
@@ -205,6 +223,24 @@ bool launch_k1_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   if (p.payload_off % rb || p.payload_bytes % rb || p.header_bytes % rb || p.frame_bytes % rb ||
       ((uintptr_t)p.frames % 16))
     return false;
+  if (pl.fast_k1_wave) {
+    // launch-relative 32-bit addressing: frames pointer moved to the frame holding block 0
+    if (p.payload_bytes < 2) return false;
+    const uint64_t fr0 = p.payload_off / p.payload_bytes;
+    const uint64_t rel0 = p.payload_off - fr0 * p.payload_bytes;
+    if (rel0 + (uint64_t)nb * pl.block_payload_bytes >= (1ull << 32)) return false;
+    KParams q = p;
+    q.frames = p.frames + fr0 * p.frame_bytes;
+    q.rel0 = (uint32_t)rel0;
+    set_fastdiv(q);
+    switch (pl.fast_k1_log2m) {
+      case 1: launch_k1_wave_t<1>(pl, q, nb, s); break;
+      case 2: launch_k1_wave_t<2>(pl, q, nb, s); break;
+      case 3: launch_k1_wave_t<3>(pl, q, nb, s); break;
+      default: return false;
+    }
+    return true;
+  }
   switch (pl.fast_k1_log2m) {
     case 1: launch_k1_fast_t<1>(pl, p, nb, s); break;
     case 2: launch_k1_fast_t<2>(pl, p, nb, s); break;
@@ -216,6 +252,15 @@ bool launch_k1_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
 }
 bool launch_k2_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   const Plan& pl = h->pl;
+  if (pl.fast_k2_wave) {
+    switch (pl.fast_k2_log2m) {
+      case 1: launch_k2_wave_t<1>(pl, p, nb, s); break;
+      case 2: launch_k2_wave_t<2>(pl, p, nb, s); break;
+      case 3: launch_k2_wave_t<3>(pl, p, nb, s); break;
+      default: return false;
+    }
+    return true;
+  }
   switch (pl.fast_k2_log2m) {
     case 1: launch_k2_fast_t<1>(pl, p, nb, s); break;
     case 2: launch_k2_fast_t<2>(pl, p, nb, s); break;
@@ -275,7 +320,12 @@ int setup_fast(frbch_handle* h) {
       }
     }
     if ((rc = upload_cf(h, &h->td1, d1)) || (rc = upload_cf(h, &h->td2, d2))) return rc;
-    switch (pl.fast_k1_log2m) {
+    if (pl.fast_k1_wave) switch (pl.fast_k1_log2m) {
+      case 1: rc = allow_lds(h, fast::frbch_k1_wave<1>, pl.k1_fast_lds); break;
+      case 2: rc = allow_lds(h, fast::frbch_k1_wave<2>, pl.k1_fast_lds); break;
+      default: rc = allow_lds(h, fast::frbch_k1_wave<3>, pl.k1_fast_lds); break;
+    }
+    else switch (pl.fast_k1_log2m) {
       case 1: rc = allow_lds(h, fast::frbch_k1_fast<1>, pl.k1_fast_lds); break;
       case 2: rc = allow_lds(h, fast::frbch_k1_fast<2>, pl.k1_fast_lds); break;
       case 3: rc = allow_lds(h, fast::frbch_k1_fast<3>, pl.k1_fast_lds); break;
@@ -287,7 +337,12 @@ int setup_fast(frbch_handle* h) {
     fft_tables(pl.c2, &t1, &t2);
     if ((rc = upload_cf(h, &h->ftw1_c, t1)) || (rc = upload_cf(h, &h->ftw2_c, t2))) return rc;
     const bool big = pl.fast_k2_nt == 1024;
-    switch (pl.fast_k2_log2m) {
+    if (pl.fast_k2_wave) switch (pl.fast_k2_log2m) {
+      case 1: rc = allow_lds(h, fast::frbch_k2_wave<1>, pl.k2_fast_lds); break;
+      case 2: rc = allow_lds(h, fast::frbch_k2_wave<2>, pl.k2_fast_lds); break;
+      default: rc = allow_lds(h, fast::frbch_k2_wave<3>, pl.k2_fast_lds); break;
+    }
+    else switch (pl.fast_k2_log2m) {
       case 1: rc = big ? allow_lds(h, fast::frbch_k2_fast<1, 1024>, pl.k2_fast_lds) : allow_lds(h, fast::frbch_k2_fast<1, 512>, pl.k2_fast_lds); break;
       case 2: rc = big ? allow_lds(h, fast::frbch_k2_fast<2, 1024>, pl.k2_fast_lds) : allow_lds(h, fast::frbch_k2_fast<2, 512>, pl.k2_fast_lds); break;
       case 3: rc = big ? allow_lds(h, fast::frbch_k2_fast<3, 1024>, pl.k2_fast_lds) : allow_lds(h, fast::frbch_k2_fast<3, 512>, pl.k2_fast_lds); break;

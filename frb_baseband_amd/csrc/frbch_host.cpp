@@ -147,17 +147,24 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit) {
     default: pl->digi_mean = 0.0f; pl->digi_scale = 1.0f; pl->digi_max = 0.0f; break;
   }
 
-  // fast path (kernels_fast.inc): lengths 512..4096 = 256*M, 16 points per thread
+  // fast path (kernels_fast.inc): lengths 512..4096 = 256*M, 16 points per (virtual) thread.
+  // wave-private variant for M <= 8 (flags & 8 selects the barrier variant instead).
   pl->fast_k1_log2m = pl->fast_k2_log2m = 0;
+  pl->fast_k1_wave = pl->fast_k2_wave = 0;
   pl->fast_k2_nt = (cfg.flags & 4u) ? 1024 : 512;
   pl->k1_fast_lds = pl->k2_fast_lds = 0;
+  const bool want_wave = !(cfg.flags & 8u);
   if (!(cfg.flags & 1u) && r >= 512 && r <= 4096) {
-    const int m = (int)r / 256, gfast = 64 / m;
+    const int m = (int)r / 256;
+    const bool wave = want_wave && m <= 8;
+    const int tps = 16 * m;
+    const int gfast = wave ? 8 * (tps < 64 ? 64 / tps : 1) : 64 / m;
     const size_t seq = (size_t)r + r / 8 + 8;
-    const size_t lds = (size_t)gfast * seq * 8 + (size_t)r * (gfast / 2);
+    const size_t lds = (size_t)gfast * seq * 8 + (size_t)r * (gfast / 2) + 128;
     const size_t generic_lds = (size_t)gfast * seq1;   // fallback for unaligned calls keeps the layout
     if (gfast <= pl->c2 && lds <= lds_limit && generic_lds <= lds_limit) {
       pl->fast_k1_log2m = ilog2(m);
+      pl->fast_k1_wave = wave ? 1 : 0;
       pl->g = gfast;
       pl->k1_lds = generic_lds;
       pl->k1_fast_lds = lds;
@@ -165,11 +172,15 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit) {
   }
   if (!(cfg.flags & 2u) && pl->c2 >= 512 && pl->c2 <= 4096 && pl->g >= 2) {
     const int m = pl->c2 / 256;
-    const int tt = pl->fast_k2_nt / (16 * m);
+    const bool wave = want_wave && m <= 8 && !(cfg.flags & 4u);
+    const int tps = 16 * m;
+    const int tt = wave ? 4 * (tps < 64 ? 64 / tps : 1) : pl->fast_k2_nt / tps;
     const size_t seq = (size_t)pl->c2 + pl->c2 / 8 + 8;
     const size_t lds = (size_t)tt * seq * 8;
-    if (tt >= 1 && pl->tscr <= tt && tt <= (int)r && (size_t)tt * pl->ncol * 4 <= lds && lds <= lds_limit) {
+    if (tt >= 1 && pl->tscr <= tt && tt <= (int)r && (size_t)tt * pl->ncol * 4 <= lds && lds <= lds_limit &&
+        (tt * pl->g) % 2 == 0) {
       pl->fast_k2_log2m = ilog2(m);
+      pl->fast_k2_wave = wave ? 1 : 0;
       pl->k2_fast_lds = lds;
     }
   }
@@ -181,6 +192,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit) {
     if (maxb > 256) maxb = 256;
   }
   if (maxb > 32768) maxb = 32768;
+  while (maxb > 1 && (uint64_t)maxb * pl->block_payload_bytes > (1ull << 31)) maxb /= 2;  // 32-bit launch-relative offsets
   pl->maxb = maxb;
   return "";
 }

@@ -27,7 +27,7 @@ struct KParams {
   int log2_nlo;       // split of the N-point twiddle table: q = hi << log2_nlo | lo
   // ---- VDIF frame stream ------------------------------------------------------------------
   uint32_t frame_bytes, header_bytes, payload_bytes;
-  uint32_t pad0;
+  uint32_t rel0;            // wave kernels: payload byte (inside frame 0 of `frames`) of block 0
   uint64_t payload_off;     // payload byte at which block 0 of this launch starts
   const uint8_t* frames;
   // ---- work buffers -------------------------------------------------------------------------
@@ -50,9 +50,10 @@ struct KParams {
   float* power_out;         // [row][nif][C] float32, output channel order
   uint8_t* code_out;        // [row][nif][C] packed to nbit, output channel order
   uint64_t row0;            // first output row of block 0 of this launch inside *_out
+  uint32_t div_magic, div_shift;  // x / payload_bytes = (t + ((x - t) >> 1)) >> div_shift, t = mulhi(magic, x)
   float lut[4];             // 2-bit level table
   float digi_mean, digi_scale, digi_max;
-  float pad1;
+  uint32_t dbg;             // timing-only ablations (cfg.flags >> 8); results are wrong when set
 };
 
 struct StatParams {

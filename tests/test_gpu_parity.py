@@ -21,6 +21,10 @@ CASES = [
     (32.0, 1024, 0.14, dict(flags=1)),                       # generic K1 + fast K2
     (32.0, 1024, 0.14, dict(flags=2)),                       # fast K1 + generic K2
     (32.0, 1024, 0.14, dict(flags=4)),                       # 1024-thread K2
+    (32.0, 1024, 0.14, dict(flags=8)),                       # barrier variants of the fast kernels
+    (-32.0, 1024, 0.14, dict(flags=8, pol=4, tscr=4)),
+    (16.0, 256, 0.04, dict(flags=8, pol=4, tscr=8)),
+    (-16.0, 512, 0.08, dict(flags=8, tscr=2)),
     (-32.0, 1024, 0.14, dict(pol=4, tscr=2)),                # BASELINE config 3 shape (-d4), LSB, -t 2
     (-32.0, 1024, 0.14, dict(pol=4, tscr=4, nbit=-32)),
     (32.0, 1024, 0.14, dict(pol=0, nbit=2, tscr=4)),
