@@ -193,7 +193,11 @@ void launch_k1_fast_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
 }
 template <int LOG2M>
 void launch_k1_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
-  hipLaunchKernelGGL(fast::frbch_k1_wave<LOG2M>, dim3(pl.c2 / pl.g, nb), dim3(512), pl.k1_fast_lds, s, p);
+  // persistent over blocks: about two workgroups' worth of groups per CU, each looping over the batch
+  const uint32_t ngrp = (uint32_t)(pl.c2 / pl.g);
+  uint32_t ny = std::max<uint32_t>(1, std::min<uint32_t>(nb, 512u / std::max<uint32_t>(1, ngrp)));
+  p.nblk = nb;
+  hipLaunchKernelGGL(fast::frbch_k1_wave<LOG2M>, dim3(ngrp, ny), dim3(512), pl.k1_fast_lds, s, p);
 }
 template <int LOG2M>
 void launch_k2_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
@@ -215,6 +219,22 @@ void launch_k2_fast_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
     hipLaunchKernelGGL((fast::frbch_k2_fast<LOG2M, 1024>), dim3(pl.r / (1024 / tps), nb), dim3(1024), pl.k2_fast_lds, s, p);
   else
     hipLaunchKernelGGL((fast::frbch_k2_fast<LOG2M, 512>), dim3(pl.r / (512 / tps), nb), dim3(512), pl.k2_fast_lds, s, p);
+}
+template <int LOG2M>
+void launch_kc_fast_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
+  const size_t lds = ((size_t)pl.c2 + pl.c2 / 8 + 8 + pl.c2) * 8;
+  hipLaunchKernelGGL(fast::frbch_kc_fast<LOG2M>, dim3(1, nb), dim3(16 << LOG2M), lds, s, p);
+}
+bool launch_kc_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
+  const Plan& pl = h->pl;
+  switch (pl.fast_k2_log2m) {   // shares the 2C-point tables of the fast K2
+    case 1: launch_kc_fast_t<1>(pl, p, nb, s); break;
+    case 2: launch_kc_fast_t<2>(pl, p, nb, s); break;
+    case 3: launch_kc_fast_t<3>(pl, p, nb, s); break;
+    case 4: launch_kc_fast_t<4>(pl, p, nb, s); break;
+    default: return false;
+  }
+  return true;
 }
 bool launch_k1_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   const Plan& pl = h->pl;
@@ -336,6 +356,14 @@ int setup_fast(frbch_handle* h) {
   if (pl.fast_k2_log2m) {
     fft_tables(pl.c2, &t1, &t2);
     if ((rc = upload_cf(h, &h->ftw1_c, t1)) || (rc = upload_cf(h, &h->ftw2_c, t2))) return rc;
+    const size_t kc_lds = ((size_t)pl.c2 + pl.c2 / 8 + 8 + pl.c2) * 8;
+    switch (pl.fast_k2_log2m) {
+      case 1: rc = allow_lds(h, fast::frbch_kc_fast<1>, kc_lds); break;
+      case 2: rc = allow_lds(h, fast::frbch_kc_fast<2>, kc_lds); break;
+      case 3: rc = allow_lds(h, fast::frbch_kc_fast<3>, kc_lds); break;
+      default: rc = allow_lds(h, fast::frbch_kc_fast<4>, kc_lds); break;
+    }
+    if (rc) return rc;
     const bool big = pl.fast_k2_nt == 1024;
     if (pl.fast_k2_wave) switch (pl.fast_k2_log2m) {
       case 1: rc = allow_lds(h, fast::frbch_k2_wave<1>, pl.k2_fast_lds); break;
@@ -353,6 +381,7 @@ int setup_fast(frbch_handle* h) {
   return FRBCH_OK;
 }
 #else
+bool launch_kc_fast(frbch_handle*, KParams&, uint32_t, dev_stream_t) { return false; }
 bool launch_k1_fast(frbch_handle*, KParams&, uint32_t, dev_stream_t) { return false; }
 bool launch_k2_fast(frbch_handle*, KParams&, uint32_t, dev_stream_t) { return false; }
 int setup_fast(frbch_handle*) { return FRBCH_OK; }
@@ -369,7 +398,7 @@ int launch_front(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   }
   {
     ProfScope ps(h, s, KID_KC, (double)nb * pl.c2 * 16.0);
-    DEV_LAUNCH(frbch_kc_dcfix, 1, nb, pl.nthreads, pl.kc_lds, s, p);
+    if (!launch_kc_fast(h, p, nb, s)) DEV_LAUNCH(frbch_kc_dcfix, 1, nb, pl.nthreads, pl.kc_lds, s, p);
   }
   CHECK_DEV(h, dev_check_launch(), "launch K1/Kc");
   return FRBCH_OK;
@@ -391,7 +420,7 @@ int ensure_powbuf(frbch_handle* h) {
   const Plan& pl = h->pl;
   h->pow_cap_rows = pl.interval_rows + (uint64_t)pl.maxb * pl.rows_per_block;
   CHECK_DEV(h, dev_malloc((void**)&h->powbuf, h->pow_cap_rows * pl.ncol * sizeof(float)), "hipMalloc(power buffer)");
-  h->partial_chunks = 256;
+  h->partial_chunks = 2048;
   CHECK_DEV(h, dev_malloc((void**)&h->partial, (size_t)h->partial_chunks * pl.ncol * 2 * sizeof(double)), "hipMalloc(partials)");
   return FRBCH_OK;
 }
@@ -407,14 +436,15 @@ int run_stats(frbch_handle* h, uint64_t rows, dev_stream_t s) {
   sp.c = pl.c;
   sp.nif = pl.nif;
   sp.flip = pl.flip;
-  sp.nchunk = (int)std::min<uint64_t>((uint64_t)h->partial_chunks, std::max<uint64_t>(1, rows / 64));
+  sp.nchunk = (int)std::min<uint64_t>((uint64_t)h->partial_chunks, std::max<uint64_t>(1, rows / 32));
   sp.rows_per_chunk = (rows + sp.nchunk - 1) / sp.nchunk;
   sp.nchunk = (int)((rows + sp.rows_per_chunk - 1) / sp.rows_per_chunk);
   sp.offset = h->offset;
   sp.scale = h->scale;
   const int gx = (int)((pl.ncol + 255) / 256);
+  const int gx4 = (int)((pl.ncol / 4 + 63) / 64);
   ProfScope ps(h, s, KID_STATS, (double)rows * pl.ncol * 4.0);
-  DEV_LAUNCH(frbch_stats_partial, gx, sp.nchunk, 256, 0, s, sp);
+  DEV_LAUNCH(frbch_stats_partial, gx4, sp.nchunk, 64, 0, s, sp);
   DEV_LAUNCH(frbch_stats_final, gx, 1, 256, 0, s, sp);
   CHECK_DEV(h, dev_check_launch(), "launch stats");
   return FRBCH_OK;
@@ -437,8 +467,7 @@ int run_quantise(frbch_handle* h, uint64_t rows, uint8_t* dst, dev_stream_t s) {
   qp.digi_mean = pl.digi_mean;
   qp.digi_scale = pl.digi_scale;
   qp.digi_max = pl.digi_max;
-  const int per = qp.nbit == 2 ? 4 : 1;
-  const uint64_t total = rows * pl.ncol / per;
+  const uint64_t total = rows * pl.ncol / 4;
   const uint64_t gx = (total + 255) / 256;
   if (gx > 0x7fffffffull) return fail(h, FRBCH_E_ARG, "rescale interval too large for one quantise launch");
   ProfScope ps(h, s, KID_QUANT, (double)rows * (pl.ncol * 4.0 + pl.row_bytes));

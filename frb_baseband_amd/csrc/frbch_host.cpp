@@ -104,7 +104,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit) {
   pl->flip = cfg.bw_mhz > 0 ? 1 : 0;
   pl->nthreads = 256;
   pl->ncol = (uint64_t)pl->nif * pl->c;
-  if (cfg.nbit_out == 2 && (pl->ncol % 4)) return "2-bit output needs nif*nchan divisible by 4";
+  if (pl->ncol % 4) return "nif*nchan must be divisible by 4";
   pl->block_payload_bytes = pl->n / 2;
   pl->rows_per_block = r / t;
   const int nb = cfg.nbit_out < 0 ? 32 : cfg.nbit_out;

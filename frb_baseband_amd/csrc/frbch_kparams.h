@@ -7,6 +7,10 @@ struct __attribute__((aligned(8))) cf {  // complex float; 8-byte aligned so LDS
   float x, y;
 };
 
+struct __attribute__((aligned(16))) f4 {  // 16-byte vector of floats for coalesced row traffic
+  float v[4];
+};
+
 enum { FRBCH_OUT_FLOAT_POWER = 0, FRBCH_OUT_CODES = 1 };
 
 struct KParams {
@@ -53,6 +57,7 @@ struct KParams {
   uint32_t div_magic, div_shift;  // x / payload_bytes = (t + ((x - t) >> 1)) >> div_shift, t = mulhi(magic, x)
   float lut[4];             // 2-bit level table
   float digi_mean, digi_scale, digi_max;
+  uint32_t nblk;            // blocks in this launch (persistent kernels loop over them)
   uint32_t dbg;             // timing-only ablations (cfg.flags >> 8); results are wrong when set
 };
 
