@@ -153,6 +153,8 @@ KParams base_params(const frbch_handle* h) {
   p.c2 = pl.c2;
   p.r = pl.r;
   p.g = pl.g;
+  p.log2_g = 0;
+  while ((1 << p.log2_g) < pl.g) ++p.log2_g;
   p.tt = pl.tt;
   p.tscr = pl.tscr;
   p.nif = pl.nif;
@@ -202,8 +204,16 @@ void launch_k1_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
 template <int LOG2M>
 void launch_k2_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
   const int tps = 16 << LOG2M;
-  const int tt = 4 * (tps < 64 ? 64 / tps : 1);
-  hipLaunchKernelGGL(fast::frbch_k2_wave<LOG2M>, dim3(pl.r / tt, nb), dim3(256), pl.k2_fast_lds, s, p);
+  const int spw = tps < 64 ? 64 / tps : 1;
+  const dim3 grid2(pl.r / (2 * spw), nb), grid4(pl.r / (4 * spw), nb);
+  const int pm = p.pol_mode == 2 ? 2 : (p.pol_mode == 4 ? 4 : 0);
+#define FRBCH_K2W(NWV, PMV, GRID) hipLaunchKernelGGL((fast::frbch_k2_wave<LOG2M, NWV, PMV>), GRID, dim3(64 * NWV), pl.k2_fast_lds, s, p)
+  if (pl.fast_k2_nw == 2) {
+    if (pm == 2) FRBCH_K2W(2, 2, grid2); else if (pm == 4) FRBCH_K2W(2, 4, grid2); else FRBCH_K2W(2, 0, grid2);
+  } else {
+    if (pm == 2) FRBCH_K2W(4, 2, grid4); else if (pm == 4) FRBCH_K2W(4, 4, grid4); else FRBCH_K2W(4, 0, grid4);
+  }
+#undef FRBCH_K2W
 }
 void set_fastdiv(KParams& p) {
   const uint32_t d = p.payload_bytes;
@@ -365,10 +375,15 @@ int setup_fast(frbch_handle* h) {
     }
     if (rc) return rc;
     const bool big = pl.fast_k2_nt == 1024;
-    if (pl.fast_k2_wave) switch (pl.fast_k2_log2m) {
-      case 1: rc = allow_lds(h, fast::frbch_k2_wave<1>, pl.k2_fast_lds); break;
-      case 2: rc = allow_lds(h, fast::frbch_k2_wave<2>, pl.k2_fast_lds); break;
-      default: rc = allow_lds(h, fast::frbch_k2_wave<3>, pl.k2_fast_lds); break;
+    if (pl.fast_k2_wave) {
+      rc = FRBCH_OK;
+#define FRBCH_ALLOW(L, NWV, PMV) if (!rc) rc = allow_lds(h, fast::frbch_k2_wave<L, NWV, PMV>, pl.k2_fast_lds)
+#define FRBCH_ALLOW_L(L) FRBCH_ALLOW(L, 2, 0); FRBCH_ALLOW(L, 2, 2); FRBCH_ALLOW(L, 2, 4); FRBCH_ALLOW(L, 4, 0); FRBCH_ALLOW(L, 4, 2); FRBCH_ALLOW(L, 4, 4)
+      if (pl.fast_k2_log2m == 1) { FRBCH_ALLOW_L(1); }
+      else if (pl.fast_k2_log2m == 2) { FRBCH_ALLOW_L(2); }
+      else { FRBCH_ALLOW_L(3); }
+#undef FRBCH_ALLOW_L
+#undef FRBCH_ALLOW
     }
     else switch (pl.fast_k2_log2m) {
       case 1: rc = big ? allow_lds(h, fast::frbch_k2_fast<1, 1024>, pl.k2_fast_lds) : allow_lds(h, fast::frbch_k2_fast<1, 512>, pl.k2_fast_lds); break;

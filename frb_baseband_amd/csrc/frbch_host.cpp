@@ -174,7 +174,15 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit) {
     const int m = pl->c2 / 256;
     const bool wave = want_wave && m <= 8 && !(cfg.flags & 4u);
     const int tps = 16 * m;
-    const int tt = wave ? 4 * (tps < 64 ? 64 / tps : 1) : pl->fast_k2_nt / tps;
+    const int spw = tps < 64 ? 64 / tps : 1;
+    // wave variant: 2 waves per workgroup (more, smaller workgroups resident per CU) when tscrunch
+    // allows it and flags & 16 does not ask for 4
+    int nw = 4;
+    if (wave && !(cfg.flags & 16u) && pl->tscr <= 2 * spw && ((2 * spw * pl->g) % 2 == 0) &&
+        (size_t)2 * spw * pl->ncol * 4 <= (size_t)2 * spw * ((size_t)pl->c2 + pl->c2 / 8 + 8) * 8)
+      nw = 2;
+    pl->fast_k2_nw = nw;
+    const int tt = wave ? nw * spw : pl->fast_k2_nt / tps;
     const size_t seq = (size_t)pl->c2 + pl->c2 / 8 + 8;
     const size_t lds = (size_t)tt * seq * 8;
     if (tt >= 1 && pl->tscr <= tt && tt <= (int)r && (size_t)tt * pl->ncol * 4 <= lds && lds <= lds_limit &&
