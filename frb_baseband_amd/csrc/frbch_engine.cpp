@@ -202,13 +202,24 @@ void launch_k1_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
   hipLaunchKernelGGL(fast::frbch_k1_wave<LOG2M>, dim3(ngrp, ny), dim3(512), pl.k1_fast_lds, s, p);
 }
 template <int LOG2M>
-void launch_k2_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
+void launch_k2_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s, uint32_t h_flags) {
   const int tps = 16 << LOG2M;
   const int spw = tps < 64 ? 64 / tps : 1;
   const dim3 grid2(pl.r / (2 * spw), nb), grid4(pl.r / (4 * spw), nb);
   const int pm = p.pol_mode == 2 ? 2 : (p.pol_mode == 4 ? 4 : 0);
 #define FRBCH_K2W(NWV, PMV, GRID) hipLaunchKernelGGL((fast::frbch_k2_wave<LOG2M, NWV, PMV>), GRID, dim3(64 * NWV), pl.k2_fast_lds, s, p)
-  if (pl.fast_k2_nw == 2) {
+  // M = 8: two waves per sequence (16 points per lane), 2 or 4 sequences per workgroup -> 16 waves per CU
+  if (LOG2M == 3 && !(h_flags & 32u)) {
+    if (pl.fast_k2_nw == 2) {
+      if (pm == 2) hipLaunchKernelGGL((fast::frbch_k2_wave<3, 4, 2, 2>), grid2, dim3(256), pl.k2_fast_lds, s, p);
+      else if (pm == 4) hipLaunchKernelGGL((fast::frbch_k2_wave<3, 4, 4, 2>), grid2, dim3(256), pl.k2_fast_lds, s, p);
+      else hipLaunchKernelGGL((fast::frbch_k2_wave<3, 4, 0, 2>), grid2, dim3(256), pl.k2_fast_lds, s, p);
+    } else {
+      if (pm == 2) hipLaunchKernelGGL((fast::frbch_k2_wave<3, 8, 2, 2>), grid4, dim3(512), pl.k2_fast_lds, s, p);
+      else if (pm == 4) hipLaunchKernelGGL((fast::frbch_k2_wave<3, 8, 4, 2>), grid4, dim3(512), pl.k2_fast_lds, s, p);
+      else hipLaunchKernelGGL((fast::frbch_k2_wave<3, 8, 0, 2>), grid4, dim3(512), pl.k2_fast_lds, s, p);
+    }
+  } else if (pl.fast_k2_nw == 2) {
     if (pm == 2) FRBCH_K2W(2, 2, grid2); else if (pm == 4) FRBCH_K2W(2, 4, grid2); else FRBCH_K2W(2, 0, grid2);
   } else {
     if (pm == 2) FRBCH_K2W(4, 2, grid4); else if (pm == 4) FRBCH_K2W(4, 4, grid4); else FRBCH_K2W(4, 0, grid4);
@@ -284,9 +295,9 @@ bool launch_k2_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   const Plan& pl = h->pl;
   if (pl.fast_k2_wave) {
     switch (pl.fast_k2_log2m) {
-      case 1: launch_k2_wave_t<1>(pl, p, nb, s); break;
-      case 2: launch_k2_wave_t<2>(pl, p, nb, s); break;
-      case 3: launch_k2_wave_t<3>(pl, p, nb, s); break;
+      case 1: launch_k2_wave_t<1>(pl, p, nb, s, h->cfg.flags); break;
+      case 2: launch_k2_wave_t<2>(pl, p, nb, s, h->cfg.flags); break;
+      case 3: launch_k2_wave_t<3>(pl, p, nb, s, h->cfg.flags); break;
       default: return false;
     }
     return true;
@@ -381,7 +392,15 @@ int setup_fast(frbch_handle* h) {
 #define FRBCH_ALLOW_L(L) FRBCH_ALLOW(L, 2, 0); FRBCH_ALLOW(L, 2, 2); FRBCH_ALLOW(L, 2, 4); FRBCH_ALLOW(L, 4, 0); FRBCH_ALLOW(L, 4, 2); FRBCH_ALLOW(L, 4, 4)
       if (pl.fast_k2_log2m == 1) { FRBCH_ALLOW_L(1); }
       else if (pl.fast_k2_log2m == 2) { FRBCH_ALLOW_L(2); }
-      else { FRBCH_ALLOW_L(3); }
+      else {
+        FRBCH_ALLOW_L(3);
+        if (!rc) rc = allow_lds(h, fast::frbch_k2_wave<3, 4, 0, 2>, pl.k2_fast_lds);
+        if (!rc) rc = allow_lds(h, fast::frbch_k2_wave<3, 4, 2, 2>, pl.k2_fast_lds);
+        if (!rc) rc = allow_lds(h, fast::frbch_k2_wave<3, 4, 4, 2>, pl.k2_fast_lds);
+        if (!rc) rc = allow_lds(h, fast::frbch_k2_wave<3, 8, 0, 2>, pl.k2_fast_lds);
+        if (!rc) rc = allow_lds(h, fast::frbch_k2_wave<3, 8, 2, 2>, pl.k2_fast_lds);
+        if (!rc) rc = allow_lds(h, fast::frbch_k2_wave<3, 8, 4, 2>, pl.k2_fast_lds);
+      }
 #undef FRBCH_ALLOW_L
 #undef FRBCH_ALLOW
     }

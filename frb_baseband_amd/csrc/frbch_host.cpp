@@ -195,8 +195,9 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit) {
 
   uint32_t maxb = cfg.max_blocks_per_launch;
   if (!maxb) {
+    // big batches amortise launches and let the persistent K1 run many iterations (2 GiB of spill)
     const uint64_t spill_per_block = pl->n * 8;
-    maxb = (uint32_t)std::max<uint64_t>(1, (128ull << 20) / spill_per_block);
+    maxb = (uint32_t)std::max<uint64_t>(1, (2048ull << 20) / spill_per_block);
     if (maxb > 256) maxb = 256;
   }
   if (maxb > 32768) maxb = 32768;

@@ -21,6 +21,9 @@ CASES = [
     (32.0, 1024, 0.14, dict(flags=1)),                       # generic K1 + fast K2
     (32.0, 1024, 0.14, dict(flags=2)),                       # fast K1 + generic K2
     (32.0, 1024, 0.14, dict(flags=4)),                       # 1024-thread K2
+    (32.0, 1024, 0.14, dict(flags=32)),                      # one wave per sequence in K2
+    (-32.0, 1024, 0.14, dict(flags=32, pol=4, tscr=4)),
+    (32.0, 1024, 0.14, dict(flags=16, pol=4)),               # 4 sequences per K2 workgroup
     (32.0, 1024, 0.14, dict(flags=8)),                       # barrier variants of the fast kernels
     (-32.0, 1024, 0.14, dict(flags=8, pol=4, tscr=4)),
     (16.0, 256, 0.04, dict(flags=8, pol=4, tscr=8)),
