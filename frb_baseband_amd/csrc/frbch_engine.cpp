@@ -195,11 +195,18 @@ void launch_k1_fast_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
 }
 template <int LOG2M>
 void launch_k1_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
-  // persistent over blocks: about two workgroups' worth of groups per CU, each looping over the batch
-  const uint32_t ngrp = (uint32_t)(pl.c2 / pl.g);
-  uint32_t ny = std::max<uint32_t>(1, std::min<uint32_t>(nb, 512u / std::max<uint32_t>(1, ngrp)));
+  // persistent over blocks: the resident workgroups each keep their branch group and loop over the batch
   p.nblk = nb;
-  hipLaunchKernelGGL(fast::frbch_k1_wave<LOG2M>, dim3(ngrp, ny), dim3(512), pl.k1_fast_lds, s, p);
+  const int kg = pl.fast_k1_g;            // branches per workgroup (<= pl.g, the layout group)
+  const uint32_t ngrp = (uint32_t)(pl.c2 / kg);
+  const uint32_t resident = 256u * (uint32_t)std::max<size_t>(1, (160 * 1024) / pl.k1_fast_lds);
+  uint32_t ny = std::max<uint32_t>(1, std::min<uint32_t>(nb, resident / std::max<uint32_t>(1, ngrp)));
+  if (LOG2M == 3 && pl.fast_k1_kind == 1)
+    hipLaunchKernelGGL((fast::frbch_k1_wave<3, 4, 1>), dim3(ngrp, ny), dim3(256), pl.k1_fast_lds, s, p);
+  else if (LOG2M == 3 && pl.fast_k1_kind == 2)
+    hipLaunchKernelGGL((fast::frbch_k1_wave<3, 8, 2>), dim3(ngrp, ny), dim3(512), pl.k1_fast_lds, s, p);
+  else
+    hipLaunchKernelGGL((fast::frbch_k1_wave<LOG2M, 8, 1>), dim3(ngrp, ny), dim3(512), pl.k1_fast_lds, s, p);
 }
 template <int LOG2M>
 void launch_k2_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s, uint32_t h_flags) {
@@ -260,7 +267,7 @@ bool launch_kc_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
 bool launch_k1_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   const Plan& pl = h->pl;
   if (!pl.fast_k1_log2m) return false;
-  const uint32_t rb = (uint32_t)pl.g / 2;   // input bytes per row piece: alignment of every piece
+  const uint32_t rb = (uint32_t)(pl.fast_k1_wave ? pl.fast_k1_g : pl.g) / 2;   // input bytes per row piece: alignment of every piece
   if (p.payload_off % rb || p.payload_bytes % rb || p.header_bytes % rb || p.frame_bytes % rb ||
       ((uintptr_t)p.frames % 16))
     return false;
@@ -362,9 +369,13 @@ int setup_fast(frbch_handle* h) {
     }
     if ((rc = upload_cf(h, &h->td1, d1)) || (rc = upload_cf(h, &h->td2, d2))) return rc;
     if (pl.fast_k1_wave) switch (pl.fast_k1_log2m) {
-      case 1: rc = allow_lds(h, fast::frbch_k1_wave<1>, pl.k1_fast_lds); break;
-      case 2: rc = allow_lds(h, fast::frbch_k1_wave<2>, pl.k1_fast_lds); break;
-      default: rc = allow_lds(h, fast::frbch_k1_wave<3>, pl.k1_fast_lds); break;
+      case 1: rc = allow_lds(h, fast::frbch_k1_wave<1, 8, 1>, pl.k1_fast_lds); break;
+      case 2: rc = allow_lds(h, fast::frbch_k1_wave<2, 8, 1>, pl.k1_fast_lds); break;
+      default:
+        rc = allow_lds(h, fast::frbch_k1_wave<3, 8, 1>, pl.k1_fast_lds);
+        if (!rc) rc = allow_lds(h, fast::frbch_k1_wave<3, 4, 1>, pl.k1_fast_lds);
+        if (!rc) rc = allow_lds(h, fast::frbch_k1_wave<3, 8, 2>, pl.k1_fast_lds);
+        break;
     }
     else switch (pl.fast_k1_log2m) {
       case 1: rc = allow_lds(h, fast::frbch_k1_fast<1>, pl.k1_fast_lds); break;

@@ -160,11 +160,20 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit) {
     const int tps = 16 * m;
     const int gfast = wave ? 8 * (tps < 64 ? 64 / tps : 1) : 64 / m;
     const size_t seq = (size_t)r + r / 8 + 8;
-    const size_t lds = (size_t)gfast * seq * 8 + (size_t)r * (gfast / 2) + 128;
+    // M = 8 experiments (flags & 64): two half-size workgroups per CU (4 branches each) filling interleaved
+    // halves of the 8-branch layout rows, with 2 waves (or, flags & 128, 1 wave) per sequence
+    int kind = 0, kg = gfast;
+    if (wave && m == 8 && (cfg.flags & 64u)) {   // experiments only: the single 8-branch workgroup measured fastest
+      kind = (cfg.flags & 128u) ? 1 : 2;
+      kg = 4;
+    }
+    const size_t lds = (size_t)kg * seq * 8 + (size_t)r * (kg / 2) + 128;
     const size_t generic_lds = (size_t)gfast * seq1;   // fallback for unaligned calls keeps the layout
     if (gfast <= pl->c2 && lds <= lds_limit && generic_lds <= lds_limit) {
       pl->fast_k1_log2m = ilog2(m);
       pl->fast_k1_wave = wave ? 1 : 0;
+      pl->fast_k1_kind = kind;
+      pl->fast_k1_g = kg;
       pl->g = gfast;
       pl->k1_lds = generic_lds;
       pl->k1_fast_lds = lds;

@@ -38,6 +38,8 @@ struct Plan {
   int fast_k2_log2m;          // 0 = generic K2, else log2(M) with 2C = 256*M
   int fast_k2_nt;             // threads per K2 workgroup (512 / 1024)
   size_t k1_fast_lds, k2_fast_lds;
+  int fast_k1_g;              // branches per wave-private K1 workgroup (<= g)
+  int fast_k1_kind;           // M = 8 only: 0 = 8 waves x 8 branches, 1 = 4 waves x 4 branches, 2 = 8 waves x 4 branches (2 waves/seq)
   int fast_k2_nw;             // waves per wave-private K2 workgroup (2 or 4)
   int fast_k1_wave, fast_k2_wave; // 1 = wave-private variant (8 / 4 waves per workgroup), 0 = barrier variant
   double rate_in;             // real samples / s / pol

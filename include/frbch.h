@@ -57,7 +57,7 @@ typedef struct frbch_config {
   uint32_t coherent;           /* -F<nchan>:D (process_vdif.py:179-180); not implemented yet  */
   int32_t device;              /* GPU ordinal (>= 0)                                          */
   uint32_t max_blocks_per_launch; /* 0 = auto; filterbank blocks batched per kernel launch    */
-  uint32_t flags;              /* debug: 1 generic K1, 2 generic K2, 4 1024-thr K2, 8 barrier kernels, 16 4-seq K2, 32 1-wave-per-seq K2; >>8 = timing-only ablations */
+  uint32_t flags;              /* debug: 1 generic K1, 2 generic K2, 4 1024-thr K2, 8 barrier kernels, 16 4-seq K2, 32 1-wave/seq K2, 64 8-branch K1, 128 1-wave/seq K1; >>8 = timing-only ablations */
   char telescope[64];          /* .hdr TELESCOPE  (process_vdif.py:123)                       */
   char source[64];             /* .hdr SOURCE     (:124)                                      */
   char ra[32];                 /* .hdr RA         (:125)                                      */
