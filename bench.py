@@ -176,8 +176,19 @@ def main():
         dom = max(timing.items(), key=lambda kv: kv[1]["total_ms"])
         name, rec = dom
         ach = rec["algorithmic_bytes"] / (rec["total_ms"] * 1e-3) / 1e9 if rec["total_ms"] > 0 else 0.0
+        # measured HBM bytes per launch of that kernel: PMC passes (FETCH_SIZE / WRITE_SIZE, collected
+        # separately with rocprofv3 by tools_profile.sh) stored per filterbank block in profiles/hbm_traffic.json
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+            rec_t = tj["kernels"].get(name)
+            if rec_t and args.nchan == 1024 and args.bw == 32.0 and args.pol == 2 and args.flags == 0:
+                per_block = (rec_t["fetch_kb_per_block"] * rec_t["fetch_correction"] + rec_t["write_kb_per_block"]) * 1024.0
+                traffic = per_block * nblocks * args.steps / max(1, rec["launches"])
+        except Exception:
+            traffic = None
         roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "avg_launch_ms": round(rec["total_ms"] / max(1, rec["launches"]), 5),
                 "algorithmic_bytes_per_launch": rec["algorithmic_bytes"] / max(1, rec["launches"]),
                 "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in timing.items()}}

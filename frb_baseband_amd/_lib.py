@@ -47,7 +47,7 @@ class FrbchInfo(C.Structure):
 
 
 class _KTiming(C.Structure):
-    _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint64), ("total_ms", C.c_double),
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double),
                 ("algorithmic_bytes", C.c_double)]
 
 

@@ -84,6 +84,7 @@ struct frbch_handle {
   // profiling
   bool profiling = false;
   std::vector<EventPair> events;
+  std::string kname[KID_COUNT];   // kernel actually launched in each slot (for the timing report)
   double acc_ms[KID_COUNT] = {0};
   double acc_bytes[KID_COUNT] = {0};
   uint64_t acc_launches[KID_COUNT] = {0};
@@ -652,6 +653,30 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
   if ((rc = upload_table(h, &h->tw_nlo, pl.n, nlo, 1))) return rc;
   if ((rc = upload_table(h, &h->tw_nhi, pl.n, std::max<uint64_t>(1, nhi), nlo))) return rc;
   if ((rc = setup_fast(h))) return rc;
+  {
+    char nm[64];
+    if (pl.fast_k1_log2m && pl.fast_k1_wave) {
+      const int nw = pl.fast_k1_kind == 1 ? 4 : 8, wps = pl.fast_k1_kind == 2 ? 2 : 1;
+      snprintf(nm, sizeof nm, "frbch_k1_wave<%d,%d,%d>", pl.fast_k1_log2m, nw, wps);
+      h->kname[KID_K1] = nm;
+    } else if (pl.fast_k1_log2m) {
+      snprintf(nm, sizeof nm, "frbch_k1_fast<%d>", pl.fast_k1_log2m);
+      h->kname[KID_K1] = nm;
+    }
+    if (pl.fast_k2_log2m) {
+      snprintf(nm, sizeof nm, "frbch_kc_fast<%d>", pl.fast_k2_log2m);
+      h->kname[KID_KC] = nm;
+      if (pl.fast_k2_wave) {
+        const bool two = pl.fast_k2_log2m == 3 && !(h->cfg.flags & 32u);
+        const int nw = two ? (pl.fast_k2_nw == 2 ? 4 : 8) : pl.fast_k2_nw;
+        const int pm = h->cfg.pol_mode == 2 ? 2 : (h->cfg.pol_mode == 4 ? 4 : 0);
+        snprintf(nm, sizeof nm, "frbch_k2_wave<%d,%d,%d,%d>", pl.fast_k2_log2m, nw, pm, two ? 2 : 1);
+      } else {
+        snprintf(nm, sizeof nm, "frbch_k2_fast<%d,%d>", pl.fast_k2_log2m, pl.fast_k2_nt);
+      }
+      h->kname[KID_K2] = nm;
+    }
+  }
 
   CHECK_DEV(h, dev_malloc((void**)&h->spill, (size_t)pl.maxb * pl.n * sizeof(cf)), "hipMalloc(spill)");
   CHECK_DEV(h, dev_malloc((void**)&h->s_dc, (size_t)pl.maxb * pl.c2 * sizeof(cf)), "hipMalloc(s_dc)");
@@ -811,7 +836,7 @@ extern "C" int frbch_get_timing(frbch_handle* h, frbch_timing* t) {
   t->size = (uint32_t)sizeof *t;
   t->nkernels = KID_COUNT;
   for (int i = 0; i < KID_COUNT; ++i) {
-    snprintf(t->k[i].name, sizeof t->k[i].name, "%s", kKernelNames[i]);
+    snprintf(t->k[i].name, sizeof t->k[i].name, "%s", h->kname[i].empty() ? kKernelNames[i] : h->kname[i].c_str());
     t->k[i].launches = h->acc_launches[i];
     t->k[i].total_ms = h->acc_ms[i];
     t->k[i].algorithmic_bytes = h->acc_bytes[i];

@@ -92,7 +92,7 @@ typedef struct frbch_timing {
   uint32_t size;
   uint32_t nkernels;
   struct {
-    char name[32];
+    char name[48];
     uint64_t launches;
     double total_ms;
     double algorithmic_bytes;  /* sum over launches of the DESIGN.md per-launch byte model      */

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Round artifacts (run on the GPU box): bench line, rocprofv3 kernel stats of the same command, HBM traffic PMC passes.
+tag=${1:-r01_final}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+out=gpurun_out/$tag
+mkdir -p $out
+timeout -k 10 400 python3 bench.py > $out/bench.json 2> $out/bench.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --no-cpu > $out/trace_bench.json 2> $out/trace.err
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py --no-cpu --steps 1 --warmup 1 > $out/fetch.log 2>&1
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py --no-cpu --steps 1 --warmup 1 > $out/write.log 2>&1
+python3 - <<PY
+import csv, glob, collections, json
+res = {}
+for name, cnt in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    for p in glob.glob("$out/%s/*/*counter_collection.csv" % name):
+        acc = collections.defaultdict(float); n = collections.Counter()
+        for row in csv.DictReader(open(p)):
+            if row["Counter_Name"] != cnt: continue
+            k = row["Kernel_Name"]
+            acc[k] += float(row["Counter_Value"]); n[k] += 1
+        for k in acc:
+            if "frbch" in k:
+                res.setdefault(k, {})[cnt + "_KB_total"] = acc[k]; res[k]["dispatches"] = n[k]
+json.dump(res, open("$out/pmc_traffic.json", "w"), indent=1)
+print(json.dumps(res, indent=1)[:3000])
+PY
+cat $out/bench.json | cut -c1-1800
