@@ -170,6 +170,18 @@ def main():
         dt = float(tmax.item())
 
     timing = c.get_timing()
+    # extra (not `value`): steady state of a long scan -- scale frozen after the first interval (-c), K2 digitises in-kernel
+    c.set_profiling(False)
+    off, sc = c.get_rescale()
+    c.reset()
+    c.set_rescale(off, sc)
+    c.process_device(frames.data_ptr(), nfr, 8032, 32, 0, nblocks, out.data_ptr(), out.numel(), stream)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        c.process_device(frames.data_ptr(), nfr, 8032, 32, 0, nblocks, out.data_ptr(), out.numel(), stream)
+    torch.cuda.synchronize()
+    steady = samples_per_step * args.steps / (time.perf_counter() - t1) / 1e6
     if rank == 0:
         total_samples = samples_per_step * args.steps * world
         value = total_samples / dt / 1e6
@@ -202,7 +214,8 @@ def main():
                                    f"(-c -b8 -d1 -F{args.nchan}:{info.freq_res}), {args.seconds:g} s per IF per step, "
                                    f"one IF per GPU, first rescale interval measured every step",
                        "samples_per_step_per_gpu": samples_per_step, "blocks_per_step": nblocks,
-                       "realtime_x": round(value / world / (2 * args.bw), 2)},
+                       "realtime_x": round(value / world / (2 * args.bw), 2),
+                       "steady_state_msamples_per_gpu": round(steady, 1)},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu:

@@ -206,6 +206,8 @@ void launch_k1_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
     hipLaunchKernelGGL((fast::frbch_k1_wave<3, 4, 1>), dim3(ngrp, ny), dim3(256), pl.k1_fast_lds, s, p);
   else if (LOG2M == 3 && pl.fast_k1_kind == 2)
     hipLaunchKernelGGL((fast::frbch_k1_wave<3, 8, 2>), dim3(ngrp, ny), dim3(512), pl.k1_fast_lds, s, p);
+  else if (LOG2M == 3 && pl.fast_k1_kind == 3)
+    hipLaunchKernelGGL((fast::frbch_k1_wave<3, 16, 2>), dim3(ngrp, ny), dim3(1024), pl.k1_fast_lds, s, p);
   else
     hipLaunchKernelGGL((fast::frbch_k1_wave<LOG2M, 8, 1>), dim3(ngrp, ny), dim3(512), pl.k1_fast_lds, s, p);
 }
@@ -376,6 +378,7 @@ int setup_fast(frbch_handle* h) {
         rc = allow_lds(h, fast::frbch_k1_wave<3, 8, 1>, pl.k1_fast_lds);
         if (!rc) rc = allow_lds(h, fast::frbch_k1_wave<3, 4, 1>, pl.k1_fast_lds);
         if (!rc) rc = allow_lds(h, fast::frbch_k1_wave<3, 8, 2>, pl.k1_fast_lds);
+        if (!rc) rc = allow_lds(h, fast::frbch_k1_wave<3, 16, 2>, pl.k1_fast_lds);
         break;
     }
     else switch (pl.fast_k1_log2m) {
@@ -515,10 +518,12 @@ int run_quantise(frbch_handle* h, uint64_t rows, uint8_t* dst, dev_stream_t s) {
   qp.digi_scale = pl.digi_scale;
   qp.digi_max = pl.digi_max;
   const uint64_t total = rows * pl.ncol / 4;
-  const uint64_t gx = (total + 255) / 256;
-  if (gx > 0x7fffffffull) return fail(h, FRBCH_E_ARG, "rescale interval too large for one quantise launch");
+  const uint64_t gx = std::min<uint64_t>((total + 256 * 4 - 1) / (256 * 4), 256 * 32);   // grid-stride, 4 groups per thread per trip
+  qp.grid_x = (uint32_t)std::max<uint64_t>(1, gx);
+  qp.log2_c = 0;
+  while ((1 << qp.log2_c) < pl.c) ++qp.log2_c;
   ProfScope ps(h, s, KID_QUANT, (double)rows * (pl.ncol * 4.0 + pl.row_bytes));
-  DEV_LAUNCH(frbch_quantise, gx, 1, 256, 0, s, qp);
+  DEV_LAUNCH(frbch_quantise, qp.grid_x, 1, 256, 0, s, qp);
   CHECK_DEV(h, dev_check_launch(), "launch quantise");
   return FRBCH_OK;
 }
@@ -656,7 +661,7 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
   {
     char nm[64];
     if (pl.fast_k1_log2m && pl.fast_k1_wave) {
-      const int nw = pl.fast_k1_kind == 1 ? 4 : 8, wps = pl.fast_k1_kind == 2 ? 2 : 1;
+      const int nw = pl.fast_k1_kind == 1 ? 4 : (pl.fast_k1_kind == 3 ? 16 : 8), wps = pl.fast_k1_kind >= 2 ? 2 : 1;
       snprintf(nm, sizeof nm, "frbch_k1_wave<%d,%d,%d>", pl.fast_k1_log2m, nw, wps);
       h->kname[KID_K1] = nm;
     } else if (pl.fast_k1_log2m) {

@@ -166,6 +166,8 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit) {
     if (wave && m == 8 && (cfg.flags & 64u)) {   // experiments only: the single 8-branch workgroup measured fastest
       kind = (cfg.flags & 128u) ? 1 : 2;
       kg = 4;
+    } else if (wave && m == 8 && (cfg.flags & 128u)) {
+      kind = 3;                                   // 16 waves, two per sequence, 8 branches
     }
     const size_t lds = (size_t)kg * seq * 8 + (size_t)r * (kg / 2) + 128;
     const size_t generic_lds = (size_t)gfast * seq1;   // fallback for unaligned calls keeps the layout

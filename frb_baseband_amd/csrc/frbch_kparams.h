@@ -80,6 +80,9 @@ struct QuantParams {
   const float* offset;
   const float* scale;
   float digi_mean, digi_scale, digi_max;
+  uint32_t grid_x;          // workgroups launched (grid-stride loop)
+  int log2_c;
 };
+#define QUANT_GRID_X(p) ((p).grid_x)
 
 #endif
