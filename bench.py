@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--flags", type=int, default=0, help="debug flags of frbch_config (see include/frbch.h)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -119,12 +121,14 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
     else:
         dist = None
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (there is no CPU fallback of the hot path)", file=sys.stderr)
         sys.exit(2)
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -165,7 +169,7 @@ def main():
     dt = time.perf_counter() - t0
     assert got_rows == rows, (got_rows, rows)
     if dist is not None:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 

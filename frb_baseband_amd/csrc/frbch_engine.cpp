@@ -215,9 +215,12 @@ template <int LOG2M>
 void launch_k2_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s, uint32_t h_flags) {
   const int tps = 16 << LOG2M;
   const int spw = tps < 64 ? 64 / tps : 1;
-  const dim3 grid2(pl.r / (2 * spw), nb), grid4(pl.r / (4 * spw), nb);
+  const dim3 grid2(pl.r / (2 * spw), nb), grid4(pl.r / (4 * spw), nb), grid8(pl.r / (8 * spw), nb);
   const int pm = p.pol_mode == 2 ? 2 : (p.pol_mode == 4 ? 4 : 0);
 #define FRBCH_K2W(NWV, PMV, GRID) hipLaunchKernelGGL((fast::frbch_k2_wave<LOG2M, NWV, PMV>), GRID, dim3(64 * NWV), pl.k2_fast_lds, s, p)
+  if (pl.fast_k2_nw == 8) {   // large tscrunch: 8 (x spw) sequences per workgroup, one wave per sequence
+    if (pm == 2) FRBCH_K2W(8, 2, grid8); else if (pm == 4) FRBCH_K2W(8, 4, grid8); else FRBCH_K2W(8, 0, grid8);
+  } else
   // M = 8: two waves per sequence (16 points per lane), 2 or 4 sequences per workgroup -> 16 waves per CU
   if (LOG2M == 3 && !(h_flags & 32u)) {
     if (pl.fast_k2_nw == 2) {
@@ -404,7 +407,7 @@ int setup_fast(frbch_handle* h) {
     if (pl.fast_k2_wave) {
       rc = FRBCH_OK;
 #define FRBCH_ALLOW(L, NWV, PMV) if (!rc) rc = allow_lds(h, fast::frbch_k2_wave<L, NWV, PMV>, pl.k2_fast_lds)
-#define FRBCH_ALLOW_L(L) FRBCH_ALLOW(L, 2, 0); FRBCH_ALLOW(L, 2, 2); FRBCH_ALLOW(L, 2, 4); FRBCH_ALLOW(L, 4, 0); FRBCH_ALLOW(L, 4, 2); FRBCH_ALLOW(L, 4, 4)
+#define FRBCH_ALLOW_L(L) FRBCH_ALLOW(L, 2, 0); FRBCH_ALLOW(L, 2, 2); FRBCH_ALLOW(L, 2, 4); FRBCH_ALLOW(L, 4, 0); FRBCH_ALLOW(L, 4, 2); FRBCH_ALLOW(L, 4, 4); FRBCH_ALLOW(L, 8, 0); FRBCH_ALLOW(L, 8, 2); FRBCH_ALLOW(L, 8, 4)
       if (pl.fast_k2_log2m == 1) { FRBCH_ALLOW_L(1); }
       else if (pl.fast_k2_log2m == 2) { FRBCH_ALLOW_L(2); }
       else {
@@ -672,7 +675,7 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
       snprintf(nm, sizeof nm, "frbch_kc_fast<%d>", pl.fast_k2_log2m);
       h->kname[KID_KC] = nm;
       if (pl.fast_k2_wave) {
-        const bool two = pl.fast_k2_log2m == 3 && !(h->cfg.flags & 32u);
+        const bool two = pl.fast_k2_log2m == 3 && !(h->cfg.flags & 32u) && pl.fast_k2_nw != 8;
         const int nw = two ? (pl.fast_k2_nw == 2 ? 4 : 8) : pl.fast_k2_nw;
         const int pm = h->cfg.pol_mode == 2 ? 2 : (h->cfg.pol_mode == 4 ? 4 : 0);
         snprintf(nm, sizeof nm, "frbch_k2_wave<%d,%d,%d,%d>", pl.fast_k2_log2m, nw, pm, two ? 2 : 1);

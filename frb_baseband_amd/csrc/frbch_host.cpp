@@ -188,10 +188,14 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit) {
     const int spw = tps < 64 ? 64 / tps : 1;
     // wave variant: 2 waves per workgroup (more, smaller workgroups resident per CU) when tscrunch
     // allows it and flags & 16 does not ask for 4
+    // sequences (time samples) per workgroup = nw*spw: the smallest of 2, 4, 8 (x spw) that holds one
+    // tscrunch group; small workgroups keep more of them resident per CU
     int nw = 4;
     if (wave && !(cfg.flags & 16u) && pl->tscr <= 2 * spw && ((2 * spw * pl->g) % 2 == 0) &&
         (size_t)2 * spw * pl->ncol * 4 <= (size_t)2 * spw * ((size_t)pl->c2 + pl->c2 / 8 + 8) * 8)
       nw = 2;
+    else if (wave && pl->tscr > 4 * spw)
+      nw = 8;
     pl->fast_k2_nw = nw;
     const int tt = wave ? nw * spw : pl->fast_k2_nt / tps;
     const size_t seq = (size_t)pl->c2 + pl->c2 / 8 + 8;

@@ -9,11 +9,14 @@ from oracle import frb_oracle as o
 #  * detected power: |P - P_oracle| <= POWER_RTOL * mean power of that (product, channel) series
 #    (fp32 FFT of up to 2^26 points against an fp64 oracle).
 #  * digitised codes: identical except where the oracle's pre-rounding value lies within
-#    CODE_TIE_EPS of a rounding boundary; such samples may differ by 1 and must stay below
-#    CODE_MISMATCH_FRAC of all samples.
+#    TIE_EPS_SIGMA (in units of the rescaled sigma, i.e. TIE_EPS_SIGMA * digi_scale code units:
+#    2e-3 of an 8-bit code, 0.5 of a 16-bit code) of a rounding boundary; such samples may differ
+#    by 1 and must stay below MISMATCH_FRAC_PER_SIGMA * digi_scale of all samples (2e-4 for 8 bit).
 POWER_RTOL = 2e-5
-CODE_TIE_EPS = 2e-3
-CODE_MISMATCH_FRAC = 2e-4
+TIE_EPS_SIGMA = 1.0e-4
+MISMATCH_FRAC_PER_SIGMA = 1.0e-5
+CODE_TIE_EPS = TIE_EPS_SIGMA * 127.5 / 6.0          # 8-bit values, kept for reference
+CODE_MISMATCH_FRAC = MISMATCH_FRAC_PER_SIGMA * 127.5 / 6.0
 RESCALE_RTOL = 2e-6
 
 
@@ -58,9 +61,10 @@ def check_codes(ref_bytes, got_bytes, ocfg):
     nbad = bad[0].size
     if nbad:
         assert np.abs(d).max() <= 1, "code differs by more than 1"
+        _mean, dscale, _vmax = o.digi_params(ocfg.nbit)
         dist = expected_boundary_distance(ocfg)[bad]
-        assert dist.max() <= CODE_TIE_EPS, f"mismatch away from a rounding tie: {dist.max()}"
-        assert nbad <= max(2, CODE_MISMATCH_FRAC * d.size), f"{nbad} of {d.size} codes differ"
+        assert dist.max() <= TIE_EPS_SIGMA * dscale, f"mismatch away from a rounding tie: {dist.max()}"
+        assert nbad <= max(2, MISMATCH_FRAC_PER_SIGMA * dscale * d.size), f"{nbad} of {d.size} codes differ"
     return nbad
 
 

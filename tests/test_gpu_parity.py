@@ -31,6 +31,10 @@ CASES = [
     (-32.0, 1024, 0.14, dict(pol=4, tscr=2)),                # BASELINE config 3 shape (-d4), LSB, -t 2
     (-32.0, 1024, 0.14, dict(pol=4, tscr=4, nbit=-32)),
     (32.0, 1024, 0.14, dict(pol=0, nbit=2, tscr=4)),
+    (32.0, 1024, 0.14, dict(tscr=8)),                        # -t 8: 8-sequence K2 workgroups
+    (-32.0, 1024, 0.14, dict(pol=4, tscr=8, nbit=16)),
+    (32.0, 1024, 0.14, dict(tscr=16)),                       # -t 16: generic K2 behind the fast K1
+    (16.0, 512, 0.08, dict(tscr=8, pol=4)),
     (32.0, 1024, 0.14, dict(pol=1, nbit=16, interval=0.0)),
     (32.0, 1024, 0.14, dict(pol=3, interval=0.05, const=0)),
     (32.0, 1024, 0.2, dict(start=0.05, maxb=2)),             # -S, odd batching
