@@ -43,6 +43,7 @@ class FrbchInfo(C.Structure):
         ("fch1_mhz", C.c_double), ("foff_mhz", C.c_double),
         ("frame_bytes", C.c_uint32), ("header_bytes", C.c_uint32),
         ("have_rescale", C.c_uint32), ("reserved", C.c_uint32),
+        ("frames_seen", C.c_uint64), ("frames_invalid", C.c_uint64), ("frame_gaps", C.c_uint64),
     ]
 
 

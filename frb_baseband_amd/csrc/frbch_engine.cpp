@@ -74,6 +74,9 @@ struct frbch_handle {
   uint64_t skip_bytes = 0;      // payload bytes still to skip before the next block starts
   uint64_t blocks_budget = 0;   // blocks still allowed by -T
   std::vector<uint8_t> carry;   // whole + partial frames not yet consumed
+  uint64_t frames_seen = 0, frames_invalid = 0, frame_gaps = 0;
+  uint64_t next_frame_index = 0;   // seconds*fps + frame_nr expected next
+  size_t checked_bytes = 0;        // prefix of `carry` whose headers were already checked
   uint8_t* d_frames = nullptr;
   size_t d_frames_cap = 0;
   uint8_t* d_out = nullptr;
@@ -733,6 +736,9 @@ extern "C" int frbch_get_info(frbch_handle* h, frbch_info* info) {
   info->frame_bytes = h->have_vdif ? h->v0.frame_bytes : 0;
   info->header_bytes = h->have_vdif ? h->v0.header_bytes() : 0;
   info->have_rescale = h->have_scale ? 1 : 0;
+  info->frames_seen = h->frames_seen;
+  info->frames_invalid = h->frames_invalid;
+  info->frame_gaps = h->frame_gaps;
   return FRBCH_OK;
 }
 
@@ -742,6 +748,9 @@ extern "C" int frbch_reset(frbch_handle* h) {
   h->pow_rows = 0;
   h->rows_out = h->blocks_done = 0;
   h->have_vdif = false;
+  h->frames_seen = h->frames_invalid = h->frame_gaps = 0;
+  h->next_frame_index = 0;
+  h->checked_bytes = 0;
   h->carry.clear();
   h->outq.clear();
   h->outq_pos = 0;
@@ -896,9 +905,36 @@ int queue_rows(frbch_handle* h, uint64_t rows) {
   return FRBCH_OK;
 }
 
+// every frame header of the stream is checked once: geometry must match the first frame (else the
+// stream is corrupt or mis-framed: error); invalid flags and frame-number jumps are only counted,
+// the data is used as is because the reference always passes -cont (process_vdif.py:157,160)
+int check_headers(frbch_handle* h) {
+  const uint64_t fb = h->v0.frame_bytes;
+  const double fps_d = h->pl.rate_in * 2.0 * 2.0 / 8.0 / h->v0.payload_bytes();
+  const uint64_t fps = (uint64_t)llround(fps_d);
+  while (h->checked_bytes + 16 <= h->carry.size()) {
+    VdifInfo v;
+    parse_vdif_header(h->carry.data() + h->checked_bytes, &v);
+    if (v.frame_bytes != h->v0.frame_bytes || v.legacy != h->v0.legacy || v.bits_per_sample != h->v0.bits_per_sample ||
+        v.log2_nchan != h->v0.log2_nchan)
+      return fail(h, FRBCH_E_FORMAT, "VDIF frame header changes geometry mid-stream (frame " + std::to_string(h->frames_seen) + ")");
+    const uint64_t idx = (uint64_t)v.seconds * fps + v.frame_nr;
+    if (h->frames_seen && idx != h->next_frame_index) h->frame_gaps++;
+    h->next_frame_index = idx + 1;
+    if (v.invalid) h->frames_invalid++;
+    h->frames_seen++;
+    h->checked_bytes += fb;
+  }
+  return FRBCH_OK;
+}
+
 int process_carry(frbch_handle* h) {
   const Plan& pl = h->pl;
   const uint64_t fb = h->v0.frame_bytes, hb = h->v0.header_bytes(), pb = h->v0.payload_bytes();
+  {
+    const int rc = check_headers(h);
+    if (rc) return rc;
+  }
   size_t consumed_frames = 0;  // frames at the front of carry that are fully used
   for (;;) {
     // drop frames that -S skips entirely
@@ -923,8 +959,14 @@ int process_carry(frbch_handle* h) {
     h->blocks_budget -= nb;
     h->skip_bytes += nb * pl.block_payload_bytes;
   }
-  if (consumed_frames) h->carry.erase(h->carry.begin(), h->carry.begin() + consumed_frames * fb);
-  if (h->blocks_budget == 0) h->carry.clear();  // -T reached: ignore the rest
+  if (consumed_frames) {
+    h->carry.erase(h->carry.begin(), h->carry.begin() + consumed_frames * fb);
+    h->checked_bytes = h->checked_bytes > consumed_frames * fb ? h->checked_bytes - consumed_frames * fb : 0;
+  }
+  if (h->blocks_budget == 0) {  // -T reached: ignore the rest
+    h->carry.clear();
+    h->checked_bytes = 0;
+  }
   return FRBCH_OK;
 }
 

@@ -84,6 +84,9 @@ typedef struct frbch_info {
   uint32_t frame_bytes, header_bytes;
   uint32_t have_rescale;       /* offset/scale are defined                                     */
   uint32_t reserved;
+  uint64_t frames_seen;        /* host streaming path: frames whose header was checked           */
+  uint64_t frames_invalid;     /* ... with the VDIF invalid bit set (data used as is: -cont)     */
+  uint64_t frame_gaps;         /* ... frame-number discontinuities (treated as contiguous: -cont) */
 } frbch_info;
 
 /* per-kernel device time accumulated since the last frbch_timing_reset (HIP events recorded on

@@ -172,3 +172,27 @@ def test_device_entry_points_and_power_tap(emu_lib):
     want = ocfg.result["power"][:, ::-1, :].transpose(2, 0, 1).reshape(-1)   # USB: flipped
     scale = ocfg.result["power"].mean()
     assert np.abs(pw - want).max() <= pu.POWER_RTOL * scale
+
+
+def test_frame_header_checks(emu_lib):
+    """invalid flags and frame-number jumps are counted and, as -cont prescribes, used as contiguous data;
+    a header whose geometry changes mid-stream is an error."""
+    raw = synth.make_vdif(0.01, bw_mhz=16.0, nchan=32).copy()
+    cfg = pu.lib_cfg(emu_lib, 16.0, 32, 0.01, freq_res=64)
+    with ch.Channeliser(cfg, emu_lib) as c:
+        clean = c.channelise_bytes(raw)
+        assert c.get_info().frames_seen == raw.size // 8032 and c.get_info().frame_gaps == 0
+    marked = raw.copy()
+    marked[3 * 8032 + 3] |= 0x80                                  # invalid bit of frame 3
+    w1 = marked[5 * 8032 + 4: 5 * 8032 + 8].view("<u4")
+    w1[0] = (w1[0] & 0xFF000000) | 1234                            # frame number jump at frame 5
+    with ch.Channeliser(cfg, emu_lib) as c:
+        got = c.channelise_bytes(marked)
+        info = c.get_info()
+    assert got == clean                                            # payload untouched: same output
+    assert info.frames_invalid == 1 and info.frame_gaps == 2       # jump in and out of the odd frame number
+    broken = raw.copy()
+    broken[7 * 8032 + 8: 7 * 8032 + 11] = 0                        # frame length field zeroed
+    with ch.Channeliser(cfg, emu_lib) as c:
+        with pytest.raises(ch.RunError):
+            c.push(broken)
