@@ -1,0 +1,142 @@
+"""GPU tests at BASELINE.json's full size (configs[1]: 10 s of a 32 MHz IF = 152 blocks of 2^22 samples)
+through size-independent properties, plus the end-to-end drop-in flows (shim into a FIFO, multi-IF scan)."""
+import contextlib
+import io
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from frb_baseband_amd import channeliser as ch
+from frb_baseband_amd import multi_if, process_vdif as pv, sigproc, synth
+from oracle import frb_oracle as o
+from tests import parity_util as pu
+from tests.hipmem import DeviceBuffer
+
+pytestmark = pytest.mark.gpu
+
+LEVEL = np.array([-3.3359, -1.0, 1.0, 3.3359])
+
+
+@pytest.fixture(scope="module")
+def ten_seconds():
+    return synth.make_vdif(10.0, bw_mhz=32.0, nchan=1024)
+
+
+def test_parseval_every_block_full_size(hip_lib, ten_seconds):
+    """sum_k sum_t (|pol0_k[t]|^2 + |pol1_k[t]|^2) of a block = R * (half-spectrum energy), and the
+    half-spectrum energy follows exactly from the time samples:
+    sum_{m<N/2} |X[m]|^2 = (N * sum x^2 + X[0]^2 - X[N/2]^2) / 2  with X[0] = sum x, X[N/2] = sum (-1)^n x."""
+    raw = ten_seconds
+    bw, nchan, r = 32.0, 1024, 2048
+    n = 2 * nchan * r
+    payload = o.strip_frames(raw, 8032, 32)
+    nblocks = payload.size * 2 // n
+    assert nblocks == 152
+    d_raw = DeviceBuffer.from_numpy(raw)
+    nfr = raw.size // 8032
+    got = np.empty(nblocks)
+    with ch.Channeliser(pu.lib_cfg(hip_lib, bw, nchan, 10.0), hip_lib) as c:
+        info = c.info
+        step = 19
+        pw = DeviceBuffer(step * info.rows_per_block * nchan * 4)
+        for b0 in range(0, nblocks, step):
+            nb = min(step, nblocks - b0)
+            c.power_device(d_raw.ptr.value, nfr, 8032, 32, b0 * info.block_payload_bytes, nb, pw.ptr.value, pw.nbytes)
+            p = pw.to_numpy(np.float32, count=nb * info.rows_per_block * nchan).reshape(nb, -1)
+            got[b0:b0 + nb] = p.astype(np.float64).sum(axis=1)
+    want = np.empty(nblocks)
+    for b in range(nblocks):
+        x = o.unpack_2bit(payload[b * n // 2:(b + 1) * n // 2])          # [2][N]
+        e = 0.0
+        for pol in range(2):
+            xs = x[pol]
+            alt = xs[0::2].sum() - xs[1::2].sum()
+            e += (n * (xs * xs).sum() + xs.sum() ** 2 - alt ** 2) / 2.0
+        want[b] = r * e
+    np.testing.assert_allclose(got, want, rtol=2e-6)
+
+
+def test_full_size_is_deterministic_and_rescale_is_reusable(hip_lib, ten_seconds):
+    raw = ten_seconds
+    cfg = pu.lib_cfg(hip_lib, 32.0, 1024, 10.0)
+    d_raw = DeviceBuffer.from_numpy(raw)
+    nfr = raw.size // 8032
+    outs = []
+    with ch.Channeliser(cfg, hip_lib) as c:
+        info = c.info
+        nblocks = (nfr * 8000) // info.block_payload_bytes
+        rows = nblocks * info.rows_per_block
+        out = DeviceBuffer(rows * info.row_bytes)
+        for _ in range(2):
+            c.reset()
+            r1 = c.process_device(d_raw.ptr.value, nfr, 8032, 32, 0, nblocks, out.ptr.value, out.nbytes)
+            r2 = c.flush_device(out.ptr.value + r1 * info.row_bytes, out.nbytes - r1 * info.row_bytes)
+            assert r1 + r2 == rows
+            outs.append(out.to_numpy(np.uint8))
+        off, sc = c.get_rescale()
+        c.reset()
+        c.set_rescale(off, sc)                     # fused path (K2 digitises) with the measured scale
+        r3 = c.process_device(d_raw.ptr.value, nfr, 8032, 32, 0, nblocks, out.ptr.value, out.nbytes)
+        assert r3 == rows
+        fused = out.to_numpy(np.uint8)
+    assert np.array_equal(outs[0], outs[1])        # run-to-run bit identical
+    assert np.array_equal(outs[0], fused)          # buffered first-interval path == fused path, same scale
+    d = outs[0].astype(np.float64)
+    assert abs(d.mean() - 127.5) < 0.6 and abs(d.std() - 127.5 / 6) < 1.5
+
+
+def test_digifil_shim_into_fifo(tmp_path):
+    """the flag-compatible `digifil` executable, driven through the harness mirror, writing into a pre-made FIFO
+    (base2fil.sh:348-349), read concurrently like `splice` would."""
+    raw = synth.make_vdif(0.14, bw_mhz=32.0, nchan=1024)
+    vd = str(tmp_path / "pr001a_ef_no0001_IF1.vdif")
+    raw.tofile(vd)
+    hdr = pv.make_hdr("R3", 1340.49, vd, pol=2, usb=False, ra="01:58:00.7502", dec="65:43:00.3152", bw=32.0,
+                      telescope="effelsberg")
+    fifodir = tmp_path / "fifos"
+    fifodir.mkdir()
+    fifo = str(fifodir / (os.path.basename(vd) + "_pol2.fil"))
+    os.mkfifo(fifo)
+    got = {}
+
+    def reader():
+        with open(fifo, "rb") as f:
+            got["data"] = f.read()
+    th = threading.Thread(target=reader)
+    th.start()
+    with contextlib.redirect_stdout(io.StringIO()):
+        ret = pv.run_digifil(hdr, str(fifodir), 0, 0.14, 1024, overwrite=True, pol=2, nbit=8, backend="shim")
+    th.join(timeout=60)
+    assert ret == str(fifodir) + "/" + os.path.basename(fifo) and os.path.exists(fifo)
+    ocfg = o.config_from_hdr(hdr, nchan=1024, total_s=0.14)
+    pu.check_codes(o.channelise(raw, ocfg), got["data"], ocfg)
+    hdr_fields = sigproc.read_fil(got["data"]).header
+    assert hdr_fields["telescope_id"] == 8 and hdr_fields["foff"] < 0 and hdr_fields["source_name"] == "R3"
+    with pytest.raises(pv.RunError), contextlib.redirect_stdout(io.StringIO()):
+        pv.run_digifil(str(tmp_path / "missing.hdr"), str(tmp_path), 0, 1, 1024, overwrite=True, backend="shim")
+
+
+def test_multi_if_scan_on_device(tmp_path):
+    d = str(tmp_path)
+    raws, vd = {}, {}
+    for i in (1, 2):
+        raws[i] = synth.make_vdif(0.14, bw_mhz=32.0, nchan=1024, if_index=i)
+        vd[i] = os.path.join(d, f"x_ef_no0001_IF{i}.vdif")
+        raws[i].tofile(vd[i])
+    with contextlib.redirect_stdout(io.StringIO()):
+        out = multi_if.process_scan(vd, freq_lsb_0=1340.0, bw=32.0, nchan=1024, nsec=0.14, out_dir=d, source="R3",
+                                    ra="01:58:00.75", dec="65:43:00.3")
+    got = sigproc.read_fil(out)
+    parts = []
+    for i in (2, 1):
+        plan = multi_if.plan_ifs(2, 1340.0, 32.0)[i - 1]
+        cfg = o.Config(bw_mhz=32.0 if plan.sideband == "u" else -32.0, freq_mhz=plan.freq_mhz, nchan=1024, total_s=0.14,
+                       source="R3", ra="01:58:00.75", dec="65:43:00.3")
+        parts.append(sigproc.read_fil(o.channelise(raws[i], cfg)))
+    want = np.concatenate([p.data for p in parts], axis=2)
+    assert got.data.shape == want.shape
+    assert np.abs(got.data.astype(int) - want.astype(int)).max() <= 1
+    assert np.count_nonzero(got.data != want) <= 2e-4 * want.size
+    assert got.header["nchans"] == 2048 and got.header["fch1"] == pytest.approx(parts[0].header["fch1"])
