@@ -1,2 +1,2 @@
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29555 bench.py --gpus 2 --steps 3 --warmup 1 --backend gloo --share-gpu --seconds 4 2>&1 | tail -2 | cut -c1-900
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "4096" 2>&1 | tail -3
+timeout -k 10 300 python bench.py --no-cpu --steps 2 --warmup 1 --nchan 4096 --bw 64 --seconds 2.2 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'], d['roofline']['kernels_ms_per_step'])"
