@@ -44,6 +44,8 @@ CASES = [
     (64.0, 2048, 0.3, dict(tscr=2)),                         # M = 16 (R = 2C = 4096), config-5 channel count
     (64.0, 2048, 0.3, dict(pol=4, tscr=4)),                  # tscrunch > fast K2 tile: generic K2 + fast K1
     (32.0, 512, 0.1, dict(freq_res=2048)),                   # R != 2C: fast K1 (M=8) + fast K2 (M=4)
+    (32.0, 1024, 0.2, dict(start=10 / 64e6)),                # -S not on a 4-byte boundary: generic K1 feeds the fast K2
+    (32.0, 1024, 0.2, dict(start=2 / 64e6, pol=4, tscr=2)),
     (64.0, 4096, 1.1, dict(tscr=8)),                         # BASELINE config 4 shape (-t 8 -F4096:8192): generic kernels, 2 blocks
 ]
 
