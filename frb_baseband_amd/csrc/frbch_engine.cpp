@@ -202,6 +202,15 @@ void launch_k1_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
   // persistent over blocks: the resident workgroups each keep their branch group and loop over the batch
   p.nblk = nb;
   const int kg = pl.fast_k1_g;            // branches per workgroup (<= pl.g, the layout group)
+  {
+    static const int ks[6] = {1, 2, 3, 4, 8, 12};
+    const int step = 64 / kg;
+    for (int i = 0; i < 6; ++i) {
+      const double a = -2.0 * M_PI * (double)((step * ks[i]) % pl.r) / (double)pl.r;
+      p.rot6[i].x = (float)cos(a);
+      p.rot6[i].y = (float)sin(a);
+    }
+  }
   const uint32_t ngrp = (uint32_t)(pl.c2 / kg);
   const uint32_t resident = 256u * (uint32_t)std::max<size_t>(1, (160 * 1024) / pl.k1_fast_lds);
   uint32_t ny = std::max<uint32_t>(1, std::min<uint32_t>(nb, resident / std::max<uint32_t>(1, ngrp)));

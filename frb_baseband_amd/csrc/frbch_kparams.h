@@ -58,6 +58,7 @@ struct KParams {
   uint32_t div_magic, div_shift;  // x / payload_bytes = (t + ((x - t) >> 1)) >> div_shift, t = mulhi(magic, x)
   float lut[4];             // 2-bit level table
   float digi_mean, digi_scale, digi_max;
+  cf rot6[6];               // K1 remapped pass: exp(-2 pi i * step * k / R), k = 1,2,3,4,8,12, step = 64/branches per WG
   uint32_t nblk;            // blocks in this launch (persistent kernels loop over them)
   uint32_t dbg;             // timing-only ablations (cfg.flags >> 8); results are wrong when set
 };
