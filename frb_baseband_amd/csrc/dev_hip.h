@@ -14,6 +14,14 @@
 #define SYNC __syncthreads()
 #define FMUL_RN(a, b) __fmul_rn((a), (b))
 #define FADD_RN(a, b) __fadd_rn((a), (b))
+// streaming (read-once / write-once) 16-byte accesses
+typedef float frbch_nf4 __attribute__((ext_vector_type(4)));
+#define LOAD_F4_STREAM(dst, ptr)                                                   \
+  do {                                                                             \
+    const frbch_nf4 t_ = __builtin_nontemporal_load((const frbch_nf4*)(ptr));      \
+    (dst).v[0] = t_.x; (dst).v[1] = t_.y; (dst).v[2] = t_.z; (dst).v[3] = t_.w;    \
+  } while (0)
+#define STORE_U32_STREAM(ptr, val) __builtin_nontemporal_store((uint32_t)(val), (uint32_t*)(ptr))
 
 typedef hipStream_t dev_stream_t;
 typedef hipEvent_t dev_event_t;

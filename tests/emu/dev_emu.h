@@ -20,6 +20,8 @@
 #define SYNC ((void)0)
 #define FMUL_RN(a, b) ((a) * (b))   /* built with -ffp-contract=off */
 #define FADD_RN(a, b) ((a) + (b))
+#define LOAD_F4_STREAM(dst, ptr) ((dst) = *(const f4*)(ptr))
+#define STORE_U32_STREAM(ptr, val) (*(uint32_t*)(ptr) = (uint32_t)(val))
 
 typedef void* dev_stream_t;
 typedef int dev_event_t;
