@@ -214,14 +214,18 @@ void launch_k1_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
   const uint32_t ngrp = (uint32_t)(pl.c2 / kg);
   const uint32_t resident = 256u * (uint32_t)std::max<size_t>(1, (160 * 1024) / pl.k1_fast_lds);
   uint32_t ny = std::max<uint32_t>(1, std::min<uint32_t>(nb, resident / std::max<uint32_t>(1, ngrp)));
-  if (LOG2M == 3 && pl.fast_k1_kind == 1)
-    hipLaunchKernelGGL((fast::frbch_k1_wave<3, 4, 1>), dim3(ngrp, ny), dim3(256), pl.k1_fast_lds, s, p);
-  else if (LOG2M == 3 && pl.fast_k1_kind == 2)
-    hipLaunchKernelGGL((fast::frbch_k1_wave<3, 8, 2>), dim3(ngrp, ny), dim3(512), pl.k1_fast_lds, s, p);
-  else if (LOG2M == 3 && pl.fast_k1_kind == 3)
-    hipLaunchKernelGGL((fast::frbch_k1_wave<3, 16, 2>), dim3(ngrp, ny), dim3(1024), pl.k1_fast_lds, s, p);
-  else
-    hipLaunchKernelGGL((fast::frbch_k1_wave<LOG2M, 8, 1>), dim3(ngrp, ny), dim3(512), pl.k1_fast_lds, s, p);
+  if constexpr (LOG2M == 4) {
+    hipLaunchKernelGGL((fast::frbch_k1_wave<4, 8, 2>), dim3(ngrp, ny), dim3(512), pl.k1_fast_lds, s, p);
+  } else {
+    if (LOG2M == 3 && pl.fast_k1_kind == 1)
+      hipLaunchKernelGGL((fast::frbch_k1_wave<3, 4, 1>), dim3(ngrp, ny), dim3(256), pl.k1_fast_lds, s, p);
+    else if (LOG2M == 3 && pl.fast_k1_kind == 2)
+      hipLaunchKernelGGL((fast::frbch_k1_wave<3, 8, 2>), dim3(ngrp, ny), dim3(512), pl.k1_fast_lds, s, p);
+    else if (LOG2M == 3 && pl.fast_k1_kind == 3)
+      hipLaunchKernelGGL((fast::frbch_k1_wave<3, 16, 2>), dim3(ngrp, ny), dim3(1024), pl.k1_fast_lds, s, p);
+    else
+      hipLaunchKernelGGL((fast::frbch_k1_wave<LOG2M, 8, 1>), dim3(ngrp, ny), dim3(512), pl.k1_fast_lds, s, p);
+  }
 }
 template <int LOG2M>
 void launch_k2_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s, uint32_t h_flags) {
@@ -230,6 +234,17 @@ void launch_k2_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s, u
   const dim3 grid2(pl.r / (2 * spw), nb), grid4(pl.r / (4 * spw), nb), grid8(pl.r / (8 * spw), nb);
   const int pm = p.pol_mode == 2 ? 2 : (p.pol_mode == 4 ? 4 : 0);
 #define FRBCH_K2W(NWV, PMV, GRID) hipLaunchKernelGGL((fast::frbch_k2_wave<LOG2M, NWV, PMV>), GRID, dim3(64 * NWV), pl.k2_fast_lds, s, p)
+  if constexpr (LOG2M == 4) {   // 2C = 4096: two waves per sequence; 2 or 4 sequences per workgroup
+    if (pl.fast_k2_nw == 2) {
+      if (pm == 2) hipLaunchKernelGGL((fast::frbch_k2_wave<4, 4, 2, 2>), grid2, dim3(256), pl.k2_fast_lds, s, p);
+      else if (pm == 4) hipLaunchKernelGGL((fast::frbch_k2_wave<4, 4, 4, 2>), grid2, dim3(256), pl.k2_fast_lds, s, p);
+      else hipLaunchKernelGGL((fast::frbch_k2_wave<4, 4, 0, 2>), grid2, dim3(256), pl.k2_fast_lds, s, p);
+    } else {
+      if (pm == 2) hipLaunchKernelGGL((fast::frbch_k2_wave<4, 8, 2, 2>), grid4, dim3(512), pl.k2_fast_lds, s, p);
+      else if (pm == 4) hipLaunchKernelGGL((fast::frbch_k2_wave<4, 8, 4, 2>), grid4, dim3(512), pl.k2_fast_lds, s, p);
+      else hipLaunchKernelGGL((fast::frbch_k2_wave<4, 8, 0, 2>), grid4, dim3(512), pl.k2_fast_lds, s, p);
+    }
+  } else {
   if (pl.fast_k2_nw == 8) {   // large tscrunch: 8 (x spw) sequences per workgroup, one wave per sequence
     if (pm == 2) FRBCH_K2W(8, 2, grid8); else if (pm == 4) FRBCH_K2W(8, 4, grid8); else FRBCH_K2W(8, 0, grid8);
   } else
@@ -248,6 +263,7 @@ void launch_k2_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s, u
     if (pm == 2) FRBCH_K2W(2, 2, grid2); else if (pm == 4) FRBCH_K2W(2, 4, grid2); else FRBCH_K2W(2, 0, grid2);
   } else {
     if (pm == 2) FRBCH_K2W(4, 2, grid4); else if (pm == 4) FRBCH_K2W(4, 4, grid4); else FRBCH_K2W(4, 0, grid4);
+  }
   }
 #undef FRBCH_K2W
 }
@@ -303,6 +319,7 @@ bool launch_k1_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
       case 1: launch_k1_wave_t<1>(pl, q, nb, s); break;
       case 2: launch_k1_wave_t<2>(pl, q, nb, s); break;
       case 3: launch_k1_wave_t<3>(pl, q, nb, s); break;
+      case 4: launch_k1_wave_t<4>(pl, q, nb, s); break;
       default: return false;
     }
     return true;
@@ -323,6 +340,7 @@ bool launch_k2_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
       case 1: launch_k2_wave_t<1>(pl, p, nb, s, h->cfg.flags); break;
       case 2: launch_k2_wave_t<2>(pl, p, nb, s, h->cfg.flags); break;
       case 3: launch_k2_wave_t<3>(pl, p, nb, s, h->cfg.flags); break;
+      case 4: launch_k2_wave_t<4>(pl, p, nb, s, h->cfg.flags); break;
       default: return false;
     }
     return true;
@@ -389,6 +407,7 @@ int setup_fast(frbch_handle* h) {
     if (pl.fast_k1_wave) switch (pl.fast_k1_log2m) {
       case 1: rc = allow_lds(h, fast::frbch_k1_wave<1, 8, 1>, pl.k1_fast_lds); break;
       case 2: rc = allow_lds(h, fast::frbch_k1_wave<2, 8, 1>, pl.k1_fast_lds); break;
+      case 4: rc = allow_lds(h, fast::frbch_k1_wave<4, 8, 2>, pl.k1_fast_lds); break;
       default:
         rc = allow_lds(h, fast::frbch_k1_wave<3, 8, 1>, pl.k1_fast_lds);
         if (!rc) rc = allow_lds(h, fast::frbch_k1_wave<3, 4, 1>, pl.k1_fast_lds);
@@ -418,8 +437,16 @@ int setup_fast(frbch_handle* h) {
     const bool big = pl.fast_k2_nt == 1024;
     if (pl.fast_k2_wave) {
       rc = FRBCH_OK;
-#define FRBCH_ALLOW(L, NWV, PMV) if (!rc) rc = allow_lds(h, fast::frbch_k2_wave<L, NWV, PMV>, pl.k2_fast_lds)
+#define FRBCH_ALLOW_(L, NWV, PMV, W) if (!rc) rc = allow_lds(h, fast::frbch_k2_wave<L, NWV, PMV, W>, pl.k2_fast_lds)
+#define FRBCH_ALLOW4(L, NWV, PMV, W) FRBCH_ALLOW_(L, NWV, PMV, W)
+#define FRBCH_ALLOW(...) FRBCH_ALLOW_SEL(__VA_ARGS__, FRBCH_ALLOW4, FRBCH_ALLOW3)(__VA_ARGS__)
+#define FRBCH_ALLOW_SEL(a, b, c, d, NAME, ...) NAME
+#define FRBCH_ALLOW3(L, NWV, PMV) FRBCH_ALLOW_(L, NWV, PMV, 1)
 #define FRBCH_ALLOW_L(L) FRBCH_ALLOW(L, 2, 0); FRBCH_ALLOW(L, 2, 2); FRBCH_ALLOW(L, 2, 4); FRBCH_ALLOW(L, 4, 0); FRBCH_ALLOW(L, 4, 2); FRBCH_ALLOW(L, 4, 4); FRBCH_ALLOW(L, 8, 0); FRBCH_ALLOW(L, 8, 2); FRBCH_ALLOW(L, 8, 4)
+      if (pl.fast_k2_log2m == 4) {
+        FRBCH_ALLOW(4, 4, 0, 2); FRBCH_ALLOW(4, 4, 2, 2); FRBCH_ALLOW(4, 4, 4, 2);
+        FRBCH_ALLOW(4, 8, 0, 2); FRBCH_ALLOW(4, 8, 2, 2); FRBCH_ALLOW(4, 8, 4, 2);
+      } else
       if (pl.fast_k2_log2m == 1) { FRBCH_ALLOW_L(1); }
       else if (pl.fast_k2_log2m == 2) { FRBCH_ALLOW_L(2); }
       else {
@@ -676,7 +703,7 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
   {
     char nm[64];
     if (pl.fast_k1_log2m && pl.fast_k1_wave) {
-      const int nw = pl.fast_k1_kind == 1 ? 4 : (pl.fast_k1_kind == 3 ? 16 : 8), wps = pl.fast_k1_kind >= 2 ? 2 : 1;
+      const int nw = pl.fast_k1_kind == 1 ? 4 : (pl.fast_k1_kind == 3 ? 16 : 8), wps = pl.fast_k1_kind >= 2 ? 2 : 1;   // kind 4: <4,8,2>
       snprintf(nm, sizeof nm, "frbch_k1_wave<%d,%d,%d>", pl.fast_k1_log2m, nw, wps);
       h->kname[KID_K1] = nm;
     } else if (pl.fast_k1_log2m) {
@@ -687,7 +714,7 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
       snprintf(nm, sizeof nm, "frbch_kc_fast<%d>", pl.fast_k2_log2m);
       h->kname[KID_KC] = nm;
       if (pl.fast_k2_wave) {
-        const bool two = pl.fast_k2_log2m == 3 && !(h->cfg.flags & 32u) && pl.fast_k2_nw != 8;
+        const bool two = (pl.fast_k2_log2m == 4) || (pl.fast_k2_log2m == 3 && !(h->cfg.flags & 32u) && pl.fast_k2_nw != 8);
         const int nw = two ? (pl.fast_k2_nw == 2 ? 4 : 8) : pl.fast_k2_nw;
         const int pm = h->cfg.pol_mode == 2 ? 2 : (h->cfg.pol_mode == 4 ? 4 : 0);
         snprintf(nm, sizeof nm, "frbch_k2_wave<%d,%d,%d,%d>", pl.fast_k2_log2m, nw, pm, two ? 2 : 1);

@@ -156,9 +156,9 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit) {
   const bool want_wave = !(cfg.flags & 8u);
   if (!(cfg.flags & 1u) && r >= 512 && r <= 4096) {
     const int m = (int)r / 256;
-    const bool wave = want_wave && m <= 8;
+    const bool wave = want_wave && m <= 16;
     const int tps = 16 * m;
-    const int gfast = wave ? 8 * (tps < 64 ? 64 / tps : 1) : 64 / m;
+    const int gfast = wave ? (m == 16 ? 4 : 8 * (tps < 64 ? 64 / tps : 1)) : 64 / m;
     const size_t seq = (size_t)r + r / 8 + 8;
     // M = 8 experiments (flags & 64): two half-size workgroups per CU (4 branches each) filling interleaved
     // halves of the 8-branch layout rows, with 2 waves (or, flags & 128, 1 wave) per sequence
@@ -168,6 +168,8 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit) {
       kg = 4;
     } else if (wave && m == 8 && (cfg.flags & 128u)) {
       kind = 3;                                   // 16 waves, two per sequence, 8 branches
+    } else if (wave && m == 16) {
+      kind = 4;                                   // R = 4096: 8 waves, two per sequence, 4 branches
     }
     const size_t lds = (size_t)kg * seq * 8 + (size_t)r * (kg / 2) + 128;
     const size_t generic_lds = (size_t)gfast * seq1;   // fallback for unaligned calls keeps the layout
@@ -183,7 +185,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit) {
   }
   if (!(cfg.flags & 2u) && pl->c2 >= 512 && pl->c2 <= 4096 && pl->g >= 2) {
     const int m = pl->c2 / 256;
-    const bool wave = want_wave && m <= 8 && !(cfg.flags & 4u);
+    const bool wave = want_wave && m <= 16 && !(cfg.flags & 4u);
     const int tps = 16 * m;
     const int spw = tps < 64 ? 64 / tps : 1;
     // wave variant: 2 waves per workgroup (more, smaller workgroups resident per CU) when tscrunch
@@ -191,7 +193,9 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit) {
     // sequences (time samples) per workgroup = nw*spw: the smallest of 2, 4, 8 (x spw) that holds one
     // tscrunch group; small workgroups keep more of them resident per CU
     int nw = 4;
-    if (wave && !(cfg.flags & 16u) && pl->tscr <= 2 * spw && ((2 * spw * pl->g) % 2 == 0) &&
+    if (wave && m == 16)
+      nw = 4;                                     // 2C = 4096: 4 time samples per workgroup (128-B gather runs), two waves each
+    else if (wave && !(cfg.flags & 16u) && pl->tscr <= 2 * spw && ((2 * spw * pl->g) % 2 == 0) &&
         (size_t)2 * spw * pl->ncol * 4 <= (size_t)2 * spw * ((size_t)pl->c2 + pl->c2 / 8 + 8) * 8)
       nw = 2;
     else if (wave && pl->tscr > 4 * spw)
