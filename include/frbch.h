@@ -57,7 +57,10 @@ typedef struct frbch_config {
   uint32_t coherent;           /* -F<nchan>:D (process_vdif.py:179-180); not implemented yet  */
   int32_t device;              /* GPU ordinal (>= 0)                                          */
   uint32_t max_blocks_per_launch; /* 0 = auto; filterbank blocks batched per kernel launch    */
-  uint32_t flags;              /* debug: 1 generic K1, 2 generic K2, 4 1024-thr K2, 8 barrier kernels, 16 4-seq K2, 32 1-wave/seq K2, 64 8-branch K1, 128 1-wave/seq K1; >>8 = timing-only ablations */
+  uint32_t flags;              /* 0 in production.  Kernel-selection switches for A/B measurements: 1 generic K1,
+                                * 2 generic K2, 4 1024-thread K2, 8 barrier (non wave-private) kernels, 16 4-sequence K2,
+                                * 32 one wave per sequence in K2, 64/128 experimental K1 shapes; bits >= 8 (flags >> 8)
+                                * are timing-only ablations that produce WRONG output (used by the profiling notes)   */
   char telescope[64];          /* .hdr TELESCOPE  (process_vdif.py:123)                       */
   char source[64];             /* .hdr SOURCE     (:124)                                      */
   char ra[32];                 /* .hdr RA         (:125)                                      */
@@ -143,7 +146,9 @@ long frbch_sigproc_header(frbch_handle* h, uint8_t* dst, size_t cap);
 /* ---- device-resident path (inputs and outputs already in HBM) ----------------------------- */
 /* d_frames: device pointer to whole VDIF frames (frame geometry taken from `frame_bytes`,
  * `header_bytes`); the payload stream is entered `payload_byte_offset` bytes after the first
- * payload byte (must be a multiple of 4); `nblocks` filterbank blocks are transformed.
+ * payload byte (any value; the fast gather needs it and the payload size to be multiples of the
+ * per-row piece, 2..16 bytes, and d_frames 16-byte aligned, else the generic kernel is used);
+ * `nblocks` filterbank blocks are transformed.  d_out / d_power must be 16-byte aligned.
  * d_out receives rows_per_block*nblocks rows of row_bytes (fewer while a rescale interval is still
  * being measured; *rows_written says how many).  `stream` is a hipStream_t (NULL = the handle's
  * own stream).  Asynchronous with respect to the host except when a rescale interval completes. */
