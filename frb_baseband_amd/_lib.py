@@ -28,6 +28,7 @@ class FrbchConfig(C.Structure):
         ("max_blocks_per_launch", C.c_uint32), ("flags", C.c_uint32),
         ("telescope", C.c_char * 64), ("source", C.c_char * 64),
         ("ra", C.c_char * 32), ("dec", C.c_char * 32), ("datafile", C.c_char * 512),
+        ("input_bits", C.c_uint32), ("reserved1", C.c_uint32),
     ]
 
 

@@ -166,6 +166,7 @@ KParams base_params(const frbch_handle* h) {
   p.nbit = h->cfg.nbit_out;
   p.flip = pl.flip;
   p.log2_nlo = pl.log2_nlo;
+  p.in_bits = pl.in_bits;
   p.spill = h->spill;
   p.s_dc = h->s_dc;
   p.p0 = h->p0;
@@ -907,11 +908,20 @@ int stream_begin(frbch_handle* h, const uint8_t* first_frame) {
   if (!check_vdif_supported(v, &why)) return fail(h, FRBCH_E_FORMAT, "unsupported VDIF stream: " + why);
   h->v0 = v;
   h->have_vdif = true;
+  if ((int)v.bits_per_sample != h->pl.in_bits) {
+    if (h->cfg.input_bits) return fail(h, FRBCH_E_FORMAT, "VDIF bits/sample differs from cfg.input_bits");
+    const std::string why2 = make_plan(h->cfg, &h->pl, h->lds_limit, (int)v.bits_per_sample);   // same sizes, other gather
+    if (!why2.empty()) return fail(h, FRBCH_E_ARG, why2);
+    CHECK_DEV(h, dev_allow_lds(frbch_k1_branch, h->pl.k1_lds), "LDS size K1");
+    CHECK_DEV(h, dev_allow_lds(frbch_k2_chan, h->pl.k2_lds), "LDS size K2");
+    h->kname[KID_K1].clear();
+  }
   const Plan& pl = h->pl;
-  const double fps = pl.rate_in * 2.0 * 2.0 / 8.0 / v.payload_bytes();
+  const uint64_t spb = 4 / (uint64_t)pl.in_bits;                       // dual-pol samples per payload byte
+  const double fps = pl.rate_in * 2.0 * pl.in_bits / 8.0 / v.payload_bytes();
   uint64_t s0 = (uint64_t)llround(h->cfg.start_s * pl.rate_in);
-  s0 -= s0 % 2;
-  h->skip_bytes = s0 / 2;
+  s0 -= s0 % spb;
+  h->skip_bytes = s0 / spb;
   const double want = h->cfg.total_s * pl.rate_in;
   h->blocks_budget = want >= 9.0e18 ? UINT64_MAX : (uint64_t)llround(want) / pl.n;
   h->tstart_mjd = (double)vdif_epoch_mjd((int)v.ref_epoch) +
@@ -946,7 +956,7 @@ int queue_rows(frbch_handle* h, uint64_t rows) {
 // the data is used as is because the reference always passes -cont (process_vdif.py:157,160)
 int check_headers(frbch_handle* h) {
   const uint64_t fb = h->v0.frame_bytes;
-  const double fps_d = h->pl.rate_in * 2.0 * 2.0 / 8.0 / h->v0.payload_bytes();
+  const double fps_d = h->pl.rate_in * 2.0 * h->pl.in_bits / 8.0 / h->v0.payload_bytes();
   const uint64_t fps = (uint64_t)llround(fps_d);
   while (h->checked_bytes + 16 <= h->carry.size()) {
     VdifInfo v;

@@ -38,7 +38,7 @@ bool parse_vdif_header(const uint8_t* buf, VdifInfo* v) {
 
 bool check_vdif_supported(const VdifInfo& v, std::string* why) {
   std::ostringstream o;
-  if (v.bits_per_sample != 2) o << "bits/sample = " << v.bits_per_sample << " (need 2); ";
+  if (v.bits_per_sample != 2 && v.bits_per_sample != 1) o << "bits/sample = " << v.bits_per_sample << " (need 1 or 2); ";
   if (v.log2_nchan != 1) o << "channels = " << (1u << v.log2_nchan) << " (need 2 = two pols); ";
   if (v.is_complex) o << "complex samples (need real); ";
   if (v.payload_bytes() % 8) o << "payload not a multiple of 8 bytes; ";
@@ -71,8 +71,11 @@ static int pow2_floor(uint64_t v) {
   return p;
 }
 
-std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit) {
+std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int in_bits) {
   std::ostringstream e;
+  if (!in_bits) in_bits = cfg.input_bits ? (int)cfg.input_bits : 2;
+  if (in_bits != 1 && in_bits != 2) return "input_bits must be 1 or 2";
+  pl->in_bits = in_bits;
   if (cfg.nchan < 2 || !is_pow2(cfg.nchan) || cfg.nchan > 8192)
     return "nchan must be a power of two in [2, 8192]";
   uint32_t r = cfg.freq_res ? cfg.freq_res : (cfg.nchan <= 128 ? 512u : 2u * cfg.nchan);
@@ -105,7 +108,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit) {
   pl->nthreads = 256;
   pl->ncol = (uint64_t)pl->nif * pl->c;
   if (pl->ncol % 4) return "nif*nchan must be divisible by 4";
-  pl->block_payload_bytes = pl->n / 2;
+  pl->block_payload_bytes = pl->n * (uint64_t)in_bits / 4;   // 2 pols x in_bits per time sample
   pl->rows_per_block = r / t;
   const int nb = cfg.nbit_out < 0 ? 32 : cfg.nbit_out;
   pl->row_bytes = pl->ncol * nb / 8;
@@ -154,7 +157,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit) {
   pl->fast_k2_nt = (cfg.flags & 4u) ? 1024 : 512;
   pl->k1_fast_lds = pl->k2_fast_lds = 0;
   const bool want_wave = !(cfg.flags & 8u);
-  if (!(cfg.flags & 1u) && r >= 512 && r <= 4096) {
+  if (!(cfg.flags & 1u) && r >= 512 && r <= 4096 && in_bits == 2) {   // the fast gather is written for 2-bit input
     const int m = (int)r / 256;
     const bool wave = want_wave && m <= 16;
     const int tps = 16 * m;

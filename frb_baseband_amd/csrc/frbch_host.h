@@ -26,6 +26,7 @@ int vdif_epoch_mjd(int ref_epoch);
 struct Plan {
   int c, r, c2, log2_c2, log2_r, log2_n, log2_nlo;
   int g, tt, tscr, nif, flip, nthreads;
+  int in_bits;                // bits per input sample (2, or 1)
   uint64_t n;                 // samples per pol per block
   uint64_t block_payload_bytes;
   uint64_t rows_per_block;
@@ -50,7 +51,7 @@ struct Plan {
 };
 
 // returns "" on success, else the reason (InputError territory)
-std::string make_plan(const frbch_config& cfg, Plan* plan, size_t lds_limit);
+std::string make_plan(const frbch_config& cfg, Plan* plan, size_t lds_limit, int in_bits = 0);
 
 std::vector<uint8_t> sigproc_header(const frbch_config& cfg, const Plan& plan, double tstart_mjd);
 double sigproc_angle(const char* text);

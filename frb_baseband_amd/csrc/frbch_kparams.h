@@ -30,6 +30,7 @@ struct KParams {
   int out_mode;       // FRBCH_OUT_FLOAT_POWER / FRBCH_OUT_CODES
   int log2_nlo;       // split of the N-point twiddle table: q = hi << log2_nlo | lo
   int log2_g;         // log2(g)
+  int in_bits;        // bits per input sample: 2 or 1
   // ---- VDIF frame stream ------------------------------------------------------------------
   uint32_t frame_bytes, header_bytes, payload_bytes;
   uint32_t rel0;            // wave kernels: payload byte (inside frame 0 of `frames`) of block 0

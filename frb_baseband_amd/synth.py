@@ -35,12 +35,12 @@ def make_states(nsamp: int, *, if_index: int = 0, nchan: int = 1024, tone_amp: f
 
 def make_vdif(seconds: float, *, bw_mhz: float = 32.0, if_index: int = 0, nchan: int = 1024,
               tone_amp: float = 0.1, payload_bytes: int = vdif.DEFAULT_PAYLOAD, legacy: int = 0,
-              seconds0: int = 1000, ref_epoch: int = 40, extra_frames: int = 0) -> np.ndarray:
+              seconds0: int = 1000, ref_epoch: int = 40, extra_frames: int = 0, bits: int = 2) -> np.ndarray:
     """Whole per-IF file as a uint8 array: ``seconds`` of data (+ ``extra_frames``; the reference's
     split adds 16, spif2file.sh:151), starting on a second boundary (spif2file.sh:148)."""
-    fps = vdif.frames_per_second(bw_mhz, payload_bytes)
+    fps = vdif.frames_per_second(bw_mhz, payload_bytes, bits)
     nfr = int(round(seconds * fps)) + extra_frames
-    spf = payload_bytes * 2                      # dual-pol time samples per frame
+    spf = payload_bytes * (4 // bits)            # dual-pol time samples per frame
     chunks = []
     per = max(1, (1 << 22) // spf) * spf         # ~4M samples per chunk, whole frames
     total = nfr * spf
@@ -49,8 +49,8 @@ def make_vdif(seconds: float, *, bw_mhz: float = 32.0, if_index: int = 0, nchan:
         n = min(per, total - s)
         st = make_states(n, if_index=if_index, nchan=nchan, tone_amp=tone_amp, sample0=s,
                          chunk=s // per)
-        chunks.append(vdif.pack_states(st))
+        chunks.append(vdif.pack_states(st) if bits == 2 else vdif.pack_states_1bit((st >= 2).astype(np.uint8)))
         s += n
     payload = np.concatenate(chunks) if chunks else np.zeros(0, np.uint8)
     return vdif.frame_payload(payload, bw_mhz=bw_mhz, seconds0=seconds0, ref_epoch=ref_epoch,
-                              payload_bytes=payload_bytes, legacy=legacy)
+                              payload_bytes=payload_bytes, legacy=legacy, bits=bits)

@@ -56,10 +56,10 @@ class VdifFrameHeader:
                    is_complex=(w3 >> 31) & 1)
 
 
-def frames_per_second(bw_mhz: float, payload_bytes: int = DEFAULT_PAYLOAD) -> int:
-    """2*|bw| Msamp/s x 2 pol x 2 bit / 8 / payload  (= bw*1e6/8000 for the standard payload;
+def frames_per_second(bw_mhz: float, payload_bytes: int = DEFAULT_PAYLOAD, bits: int = 2) -> int:
+    """2*|bw| Msamp/s x 2 pol x nbit / 8 / payload  (= bw*1e6/8000 for 2 bit and the standard payload;
     base2fil.sh:251,400-401)."""
-    fps = abs(bw_mhz) * 1.0e6 * 2 * 2 * 2 / 8 / payload_bytes
+    fps = abs(bw_mhz) * 1.0e6 * 2 * 2 * bits / 8 / payload_bytes
     if abs(fps - round(fps)) > 1e-9:
         raise ValueError(f"bw={bw_mhz} MHz does not give an integer frame rate for "
                          f"{payload_bytes}-byte payloads")
@@ -76,13 +76,23 @@ def pack_states(states: np.ndarray) -> np.ndarray:
     return (s[0, 0::2] | (s[1, 0::2] << 2) | (s[0, 1::2] << 4) | (s[1, 1::2] << 6)).astype(np.uint8)
 
 
+def pack_states_1bit(states: np.ndarray) -> np.ndarray:
+    """u8[2][nsamp] states 0/1 -> payload bytes u8[nsamp/4]: bit 2i = pol0 sample i, bit 2i+1 = pol1 sample i."""
+    assert states.shape[0] == 2 and states.shape[1] % 4 == 0
+    s = states.astype(np.uint8)
+    out = np.zeros(states.shape[1] // 4, dtype=np.uint8)
+    for i in range(4):
+        out |= (s[0, i::4] << (2 * i)) | (s[1, i::4] << (2 * i + 1))
+    return out
+
+
 def frame_payload(payload: np.ndarray, *, bw_mhz: float, seconds0: int = 0, ref_epoch: int = 40,
                   frame0: int = 0, payload_bytes: int = DEFAULT_PAYLOAD, legacy: int = 0,
-                  station_id: int = 0x4566) -> np.ndarray:
+                  station_id: int = 0x4566, bits: int = 2) -> np.ndarray:
     """Wrap a payload byte stream (whole frames) in VDIF headers -> u8 frame stream."""
     assert payload.size % payload_bytes == 0, "payload must be a whole number of frames"
     nfr = payload.size // payload_bytes
-    fps = frames_per_second(bw_mhz, payload_bytes)
+    fps = frames_per_second(bw_mhz, payload_bytes, bits)
     hb = 16 if legacy else 32
     out = np.empty((nfr, hb + payload_bytes), dtype=np.uint8)
     out[:, hb:] = payload.reshape(nfr, payload_bytes)
@@ -93,6 +103,6 @@ def frame_payload(payload: np.ndarray, *, bw_mhz: float, seconds0: int = 0, ref_
     words[:, 0] = (np.uint32(legacy) << 30) | (secs & 0x3FFFFFFF)
     words[:, 1] = (np.uint32(ref_epoch & 0x3F) << 24) | (fnr & 0xFFFFFF)
     words[:, 2] = (np.uint32(1) << 24) | np.uint32((hb + payload_bytes) // 8)
-    words[:, 3] = (np.uint32(1) << 26) | np.uint32(station_id & 0xFFFF)
+    words[:, 3] = (np.uint32(bits - 1) << 26) | np.uint32(station_id & 0xFFFF)
     out[:, :hb] = words.view(np.uint8).reshape(nfr, hb)
     return out.reshape(-1)

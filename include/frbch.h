@@ -66,6 +66,9 @@ typedef struct frbch_config {
   char ra[32];                 /* .hdr RA         (:125)                                      */
   char dec[32];                /* .hdr DEC        (:126)                                      */
   char datafile[512];          /* .hdr DATAFILE   (:129)                                      */
+  uint32_t input_bits;         /* bits per sample of the VDIF: 2, or 1 (mode VDIF_8000-1024-16-1, spif2file.sh:58-61);
+                                * 0 = take it from the first frame header (host paths) / 2 (device paths)            */
+  uint32_t reserved1;
 } frbch_config;
 
 typedef struct frbch_handle frbch_handle;

@@ -147,6 +147,24 @@ def unpack_2bit(payload: np.ndarray) -> np.ndarray:
     return out
 
 
+LEVELS_1BIT = np.array([-1.0, 1.0], dtype=np.float64)
+
+
+def unpack_1bit(payload: np.ndarray) -> np.ndarray:
+    """u8[nbytes] -> f64[2][4*nbytes]: 1-bit, 2-channel VDIF (mode VDIF_8000-1024-16-1, spif2file.sh:58-61):
+    bit 2i = pol0 sample i, bit 2i+1 = pol1 sample i (i = 0..3, LSB first); 0 -> -1, 1 -> +1."""
+    b = payload.astype(np.uint8)
+    out = np.empty((2, b.size * 4), dtype=np.float64)
+    for i in range(4):
+        out[0, i::4] = LEVELS_1BIT[(b >> (2 * i)) & 1]
+        out[1, i::4] = LEVELS_1BIT[(b >> (2 * i + 1)) & 1]
+    return out
+
+
+def unpack(payload: np.ndarray, bits: int) -> np.ndarray:
+    return unpack_1bit(payload) if bits == 1 else unpack_2bit(payload)
+
+
 # --------------------------------------------------------------------------------------------
 # Filterbank (A5 + A6): -F C:R
 # --------------------------------------------------------------------------------------------
@@ -364,13 +382,15 @@ def detected_power(raw_frames: np.ndarray, cfg: Config):
     c = cfg.nchan
     r = cfg.freq_res or freq_res_for(c)
     n = 2 * c * r
+    bits = hdr.bits_per_sample
+    spb = 4 // bits                                   # dual-pol time samples per payload byte
     s0 = int(round(cfg.start_s * rate))
-    s0 -= s0 % 2                                      # byte aligned (2 time samples per byte)
-    navail = payload.size * 2 - s0
+    s0 -= s0 % spb                                    # byte aligned
+    navail = payload.size * spb - s0
     nwant = int(round(cfg.total_s * rate))
     nsamp = max(0, min(navail, nwant))
     nblocks = nsamp // n
-    x = unpack_2bit(payload[s0 // 2: s0 // 2 + nblocks * n // 2])
+    x = unpack(payload[s0 // spb: s0 // spb + nblocks * n // spb], bits)
     out = []
     for b in range(nblocks):
         y = filterbank_block(x[:, b * n:(b + 1) * n], c, r)
@@ -386,7 +406,7 @@ def channelise(raw_frames: np.ndarray, cfg: Config) -> bytes:
     nif, c, nt = p.shape
     tsamp_s = c * cfg.tscrunch / (abs(cfg.bw_mhz) * 1.0e6)
     rate = 2.0e6 * abs(cfg.bw_mhz)
-    fps = rate * 2 * 2 / 8 / hdr.payload_bytes        # frames per second for 2 pol x 2 bit
+    fps = rate * 2 * hdr.bits_per_sample / 8 / hdr.payload_bytes   # frames per second for 2 pol x nbit
     tstart = (vdif_epoch_mjd(hdr.ref_epoch)
               + (hdr.seconds + hdr.frame_nr / fps + s0 / rate) / 86400.0)
 

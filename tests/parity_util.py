@@ -70,7 +70,9 @@ def check_codes(ref_bytes, got_bytes, ocfg):
 
 def run_streaming_case(lib, bw, nchan, secs, **kw):
     """oracle .fil vs library .fil through push/flush/pull; returns mismatch count"""
-    raw = synth.make_vdif(secs + kw.get("start", 0.0), bw_mhz=abs(bw), nchan=nchan)
+    kw = dict(kw)
+    gen = {k: kw.pop(k) for k in ("bits", "payload_bytes", "legacy") if k in kw}    # input-format variants
+    raw = synth.make_vdif(secs + kw.get("start", 0.0), bw_mhz=abs(bw), nchan=nchan, **gen)
     ocfg = oracle_cfg(bw, nchan, secs, **{k: v for k, v in kw.items() if k not in ("maxb", "flags")})
     ref = o.channelise(raw, ocfg)
     cfg = lib_cfg(lib, bw, nchan, secs, **kw)

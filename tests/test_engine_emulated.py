@@ -25,6 +25,10 @@ CASES = [
     (16.0, 16, 0.02, dict(freq_res=16, tscr=16)),            # tscrunch == freq_res: one row per block
     (32.0, 256, 0.03, dict(tscr=8)),                          # tscrunch > K2 sub-tile: LDS accumulators
     (16.0, 32, 0.03, dict(freq_res=64, start=0.01)),          # -S inside the file
+    (16.0, 32, 0.03, dict(freq_res=64, bits=1)),              # 1-bit mode VDIF_8000-1024-16-1 (spif2file.sh:58-61)
+    (-16.0, 64, 0.03, dict(pol=4, bits=1, start=0.01 + 2 / 32e6)),  # 1 bit, LSB, -S not on a byte boundary
+    (16.0, 32, 0.03, dict(freq_res=64, payload_bytes=10000)), # Mark5B-sized payload (spif2file.sh mode table)
+    (16.0, 32, 0.03, dict(freq_res=64, payload_bytes=1000, legacy=1, bits=1)),
 ]
 
 
@@ -60,6 +64,26 @@ def test_total_seconds_limits_output(emu_lib):
         with ch.Channeliser(pu.lib_cfg(emu_lib, 16.0, 32, secs, freq_res=64), emu_lib) as c:
             got = c.channelise_bytes(raw)
         pu.check_codes(ref, got, ocfg)
+
+
+def test_input_bits_pinned_or_automatic(emu_lib):
+    raw1 = synth.make_vdif(0.03, bw_mhz=16.0, nchan=32, bits=1)
+    auto = pu.lib_cfg(emu_lib, 16.0, 32, 0.03, freq_res=64)
+    assert auto.input_bits == 0
+    with ch.Channeliser(auto, emu_lib) as c:
+        want = c.channelise_bytes(raw1)
+        assert c.get_info().block_payload_bytes == 2 * 32 * 64 // 4          # N/4 bytes per block at 1 bit
+    pinned = pu.lib_cfg(emu_lib, 16.0, 32, 0.03, freq_res=64)
+    pinned.input_bits = 1
+    with ch.Channeliser(pinned, emu_lib) as c:
+        assert c.channelise_bytes(raw1) == want
+    pinned.input_bits = 2                                                    # stream says 1: refuse, don't misread
+    with ch.Channeliser(pinned, emu_lib) as c:
+        with pytest.raises(ch.RunError):
+            c.channelise_bytes(raw1)
+    pinned.input_bits = 3
+    with pytest.raises(ch.InputError):
+        ch.Channeliser(pinned, emu_lib)
 
 
 def test_empty_and_short_inputs(emu_lib):

@@ -46,6 +46,9 @@ CASES = [
     (32.0, 512, 0.1, dict(freq_res=2048)),                   # R != 2C: fast K1 (M=8) + fast K2 (M=4)
     (32.0, 1024, 0.2, dict(start=10 / 64e6)),                # -S not on a 4-byte boundary: generic K1 feeds the fast K2
     (32.0, 1024, 0.2, dict(start=2 / 64e6, pol=4, tscr=2)),
+    (32.0, 1024, 0.2, dict(bits=1, pol=4, tscr=2)),          # 1-bit mode VDIF_8000-1024-16-1: generic K1 gather feeds the fast K2
+    (-16.0, 128, 0.05, dict(bits=1, start=0.0101)),
+    (32.0, 1024, 0.2, dict(payload_bytes=10000)),            # Mark5B-sized payload through the fast kernels
     (64.0, 4096, 1.1, dict(tscr=8)),                         # BASELINE config 4 shape (-t 8 -F4096:8192): generic kernels, 2 blocks
 ]
 
