@@ -105,6 +105,10 @@ def main():
     ap.add_argument("--nchan", type=int, default=1024)
     ap.add_argument("--bw", type=float, default=32.0)
     ap.add_argument("--pol", type=int, default=2)
+    ap.add_argument("--dm", type=float, default=0.0)
+    ap.add_argument("--coherent", action="store_true", help="-F C:D: coherent dedispersion inside the filterbank (cfg 5)")
+    ap.add_argument("--freq", type=float, default=1608.0, help="centre sky frequency, MHz (matters with --coherent)")
+    ap.add_argument("--freq-res", type=int, default=0)
     ap.add_argument("--maxb", type=int, default=0, help="filterbank blocks per kernel launch (0 = library default)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
@@ -135,16 +139,17 @@ def main():
     from frb_baseband_amd import channeliser as ch
     cfg = ch.new_config(bw_mhz=args.bw, nchan=args.nchan, pol_mode=args.pol, nbit_out=8, tscrunch=1,
                         rescale_constant=1, rescale_interval_s=10.0, total_s=args.seconds, device=local_rank,
-                        max_blocks_per_launch=args.maxb, flags=args.flags)
+                        max_blocks_per_launch=args.maxb, flags=args.flags, dm=args.dm,
+                        coherent=1 if args.coherent else 0, freq_mhz=args.freq, freq_res=args.freq_res)
     c = ch.Channeliser(cfg)
     info = c.info
     frames, nfr = synth_frames_device(torch, dev, args.seconds, args.bw, args.nchan, if_index=rank)
     torch.cuda.synchronize()   # the library runs on its own stream: inputs must be complete
-    nblocks = (nfr * 8000) // info.block_payload_bytes
+    nblocks = (nfr * 8000 - info.block_payload_bytes) // info.block_stride_bytes + 1   # overlap-save when --coherent
     rows = nblocks * info.rows_per_block
     out = torch.empty(rows * info.row_bytes, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    samples_per_step = nblocks * info.block_samples
+    samples_per_step = nblocks * info.block_stride_bytes * 2      # new dual-pol samples consumed (2-bit: 2 per byte)
 
     def step():
         c.reset()
@@ -198,7 +203,7 @@ def main():
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
             rec_t = tj["kernels"].get(name)
-            if rec_t and args.nchan == 1024 and args.bw == 32.0 and args.pol == 2 and args.flags == 0:
+            if rec_t and args.nchan == 1024 and args.bw == 32.0 and args.pol == 2 and args.flags == 0 and not args.coherent:
                 per_block = (rec_t["fetch_kb_per_block"] * rec_t["fetch_correction"] + rec_t["write_kb_per_block"]) * 1024.0
                 traffic = per_block * nblocks * args.steps / max(1, rec["launches"])
         except Exception:
@@ -215,7 +220,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{world} IF x {args.bw:g} MHz 2-bit dual-pol VDIF -> {args.nchan}-ch "
                                    f"{'Stokes-I' if args.pol == 2 else 'pol%d' % args.pol} 8-bit .fil "
-                                   f"(-c -b8 -d1 -F{args.nchan}:{info.freq_res}), {args.seconds:g} s per IF per step, "
+                                   f"(-c -b8 -d1 -F{args.nchan}:{info.freq_res}"
+                                   f"{' -D %g -F%d:D' % (args.dm, args.nchan) if args.coherent else ''}), {args.seconds:g} s per IF per step, "
                                    f"one IF per GPU, first rescale interval measured every step",
                        "samples_per_step_per_gpu": samples_per_step, "blocks_per_step": nblocks,
                        "realtime_x": round(value / world / (2 * args.bw), 2),

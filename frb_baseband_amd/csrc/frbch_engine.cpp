@@ -31,9 +31,9 @@ using namespace frbch;
 
 namespace {
 
-enum { KID_K1 = 0, KID_KC, KID_K2, KID_STATS, KID_QUANT, KID_COUNT };
+enum { KID_K1 = 0, KID_KC, KID_K2, KID_STATS, KID_QUANT, KID_K3, KID_K4, KID_COUNT };
 const char* const kKernelNames[KID_COUNT] = {"frbch_k1_branch", "frbch_kc_dcfix", "frbch_k2_chan",
-                                             "frbch_stats", "frbch_quantise"};
+                                             "frbch_stats", "frbch_quantise", "frbch_k3_dedisp", "frbch_k4_out"};
 
 struct EventPair {
   dev_event_t a, b;
@@ -56,6 +56,9 @@ struct frbch_handle {
   cf *ftw1_r = nullptr, *ftw2_r = nullptr, *ftw1_c = nullptr, *ftw2_c = nullptr, *td1 = nullptr, *td2 = nullptr;
   // per-launch work buffers
   cf *spill = nullptr, *s_dc = nullptr, *p0 = nullptr;
+  // coherent dedispersion (-F C:D): second spill, kernel table, channel-major power
+  cf *spill2 = nullptr, *chirp = nullptr;
+  float* ptmp = nullptr;
   // rescale state
   float *offset = nullptr, *scale = nullptr;
   bool have_scale = false;     // offset/scale are defined
@@ -190,6 +193,13 @@ KParams base_params(const frbch_handle* h) {
   p.digi_scale = pl.digi_scale;
   p.digi_max = pl.digi_max;
   p.dbg = h->cfg.flags >> 8;
+  p.coherent = pl.coherent;
+  p.nfilt_pos = pl.nfilt_pos;
+  p.keep = pl.keep;
+  p.hop = pl.hop;
+  p.spill2 = h->spill2;
+  p.chirp = h->chirp;
+  p.ptmp = h->ptmp;
   return p;
 }
 
@@ -486,9 +496,9 @@ int launch_front(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
     const double bytes = (double)nb * ((double)pl.block_payload_bytes * p.frame_bytes / p.payload_bytes +
                                        (double)pl.n * 8.0 + (double)pl.c2 * 8.0);
     ProfScope ps(h, s, KID_K1, bytes);
-    if (!launch_k1_fast(h, p, nb, s)) DEV_LAUNCH(frbch_k1_branch, pl.c2 / pl.g, nb, pl.nthreads, pl.k1_lds, s, p);
+    if (pl.coherent || !launch_k1_fast(h, p, nb, s)) DEV_LAUNCH(frbch_k1_branch, pl.c2 / pl.g, nb, pl.nthreads, pl.k1_lds, s, p);
   }
-  {
+  if (!pl.coherent) {
     ProfScope ps(h, s, KID_KC, (double)nb * pl.c2 * 16.0);
     if (!launch_kc_fast(h, p, nb, s)) DEV_LAUNCH(frbch_kc_dcfix, 1, nb, pl.nthreads, pl.kc_lds, s, p);
   }
@@ -501,6 +511,24 @@ int launch_back(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   const int tile_t = std::max(pl.tt, pl.tscr);
   const double out_b = p.out_mode == FRBCH_OUT_FLOAT_POWER ? (double)pl.ncol * 4.0 : (double)pl.row_bytes;
   const double bytes = (double)nb * ((double)pl.n * 8.0 + (double)pl.rows_per_block * out_b);
+  if (pl.coherent) {   // K2c (branches -> channels, x kernel), K3 (back to time, detect), K4 (time-major rows)
+    {
+      ProfScope ps(h, s, KID_K2, (double)nb * (double)pl.n * 24.0);
+      DEV_LAUNCH(frbch_k2c_chirp, pl.r / pl.tt, nb, pl.nthreads, pl.k2_lds, s, p);
+    }
+    {
+      ProfScope ps(h, s, KID_K3, (double)nb * ((double)pl.n * 8.0 + (double)pl.rows_per_block * pl.ncol * 4.0));
+      DEV_LAUNCH(frbch_k3_dedisp, pl.c, nb, pl.nthreads, pl.k3_lds, s, p);
+    }
+    {
+      ProfScope ps(h, s, KID_K4, (double)nb * (double)pl.rows_per_block * (pl.ncol * 4.0 + out_b));
+      const int tc = pl.ncol < 64 ? (int)pl.ncol : 64;
+      const int gx = (int)((pl.rows_per_block + 63) / 64) * (int)(pl.ncol / tc);
+      DEV_LAUNCH(frbch_k4_out, gx, nb, pl.nthreads, pl.k4_lds, s, p);
+    }
+    CHECK_DEV(h, dev_check_launch(), "launch K2c/K3/K4");
+    return FRBCH_OK;
+  }
   ProfScope ps(h, s, KID_K2, bytes);
   if (!launch_k2_fast(h, p, nb, s)) DEV_LAUNCH(frbch_k2_chan, pl.r / tile_t, nb, pl.nthreads, pl.k2_lds, s, p);
   CHECK_DEV(h, dev_check_launch(), "launch K2");
@@ -615,7 +643,7 @@ int engine_feed(frbch_handle* h, const uint8_t* d_frames, uint32_t frame_bytes, 
     p.frame_bytes = frame_bytes;
     p.header_bytes = header_bytes;
     p.payload_bytes = frame_bytes - header_bytes;
-    p.payload_off = payload_off + b0 * pl.block_payload_bytes;
+    p.payload_off = payload_off + b0 * pl.block_stride_bytes;
     int rc = launch_front(h, p, nb, s);
     if (rc) return rc;
     const uint64_t rows = (uint64_t)nb * pl.rows_per_block;
@@ -729,6 +757,26 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
   CHECK_DEV(h, dev_malloc((void**)&h->spill, (size_t)pl.maxb * pl.n * sizeof(cf)), "hipMalloc(spill)");
   CHECK_DEV(h, dev_malloc((void**)&h->s_dc, (size_t)pl.maxb * pl.c2 * sizeof(cf)), "hipMalloc(s_dc)");
   CHECK_DEV(h, dev_malloc((void**)&h->p0, (size_t)pl.maxb * pl.c2 * sizeof(cf)), "hipMalloc(p0)");
+  if (pl.coherent) {
+    CHECK_DEV(h, dev_allow_lds(frbch_k2c_chirp, pl.k2_lds), "LDS size K2c");
+    CHECK_DEV(h, dev_allow_lds(frbch_k3_dedisp, pl.k3_lds), "LDS size K3");
+    CHECK_DEV(h, dev_malloc((void**)&h->spill2, (size_t)pl.maxb * pl.n * sizeof(cf)), "hipMalloc(spill2)");
+    CHECK_DEV(h, dev_malloc((void**)&h->chirp, (size_t)pl.n * sizeof(cf)), "hipMalloc(chirp)");
+    CHECK_DEV(h, dev_malloc((void**)&h->ptmp, (size_t)pl.maxb * pl.rows_per_block * pl.ncol * sizeof(float)), "hipMalloc(ptmp)");
+    ChirpParams cp;
+    memset(&cp, 0, sizeof cp);
+    cp.chirp = h->chirp;
+    cp.c = pl.c; cp.c2 = pl.c2; cp.r = pl.r; cp.log2_r = pl.log2_r;
+    cp.usb = h->cfg.bw_mhz > 0 ? 1 : 0;
+    const double abw = fabs(h->cfg.bw_mhz);
+    cp.band_edge_mhz = cp.usb ? h->cfg.freq_mhz - abw / 2.0 : h->cfg.freq_mhz + abw / 2.0;
+    cp.df_mhz = abw / pl.c;
+    cp.dm_over_k = h->cfg.dm / kDmDispersion;
+    DEV_LAUNCH(frbch_chirp_build, (pl.n + 255) / 256, 1, 256, 0, h->stream, cp);
+    CHECK_DEV(h, dev_check_launch(), "launch chirp build");
+    CHECK_DEV(h, dev_sync(h->stream), "sync");
+    h->kname[KID_K2] = "frbch_k2c_chirp";
+  }
   CHECK_DEV(h, dev_malloc((void**)&h->offset, pl.ncol * sizeof(float)), "hipMalloc(offset)");
   CHECK_DEV(h, dev_malloc((void**)&h->scale, pl.ncol * sizeof(float)), "hipMalloc(scale)");
   if ((rc = set_identity_rescale(h))) return rc;
@@ -746,6 +794,7 @@ extern "C" void frbch_close(frbch_handle* h) {
   dev_free(h->tw_r); dev_free(h->tw_c2); dev_free(h->tw_nhi); dev_free(h->tw_nlo);
   dev_free(h->ftw1_r); dev_free(h->ftw2_r); dev_free(h->ftw1_c); dev_free(h->ftw2_c); dev_free(h->td1); dev_free(h->td2);
   dev_free(h->spill); dev_free(h->s_dc); dev_free(h->p0);
+  dev_free(h->spill2); dev_free(h->chirp); dev_free(h->ptmp);
   dev_free(h->offset); dev_free(h->scale); dev_free(h->powbuf); dev_free(h->partial);
   dev_free(h->d_frames); dev_free(h->d_out);
   if (h->stream) dev_stream_destroy(h->stream);
@@ -776,6 +825,9 @@ extern "C" int frbch_get_info(frbch_handle* h, frbch_info* info) {
   info->frames_seen = h->frames_seen;
   info->frames_invalid = h->frames_invalid;
   info->frame_gaps = h->frame_gaps;
+  info->block_stride_bytes = pl.block_stride_bytes;
+  info->nfilt_pos = (uint32_t)pl.nfilt_pos;
+  info->nfilt_neg = (uint32_t)pl.nfilt_neg;
   return FRBCH_OK;
 }
 
@@ -825,7 +877,7 @@ extern "C" int frbch_process_device(frbch_handle* h, const void* d_frames, size_
                                     void* d_out, size_t out_cap_bytes, uint64_t* rows_written, void* stream) {
   if (!h || !d_frames || !rows_written || frame_bytes <= header_bytes) return FRBCH_E_ARG;
   const uint64_t payload = (uint64_t)nframes * (frame_bytes - header_bytes);
-  if (payload_byte_offset + nblocks * h->pl.block_payload_bytes > payload)
+  if (nblocks && payload_byte_offset + (nblocks - 1) * h->pl.block_stride_bytes + h->pl.block_payload_bytes > payload)
     return fail(h, FRBCH_E_ARG, "frames do not cover the requested blocks");
   if (nblocks && !d_out) return FRBCH_E_ARG;
   dev_stream_t s = stream ? (dev_stream_t)stream : h->stream;
@@ -846,7 +898,7 @@ extern "C" int frbch_power_device(frbch_handle* h, const void* d_frames, size_t 
   if (!h || !d_frames || !d_power || frame_bytes <= header_bytes) return FRBCH_E_ARG;
   const Plan& pl = h->pl;
   const uint64_t payload = (uint64_t)nframes * (frame_bytes - header_bytes);
-  if (payload_byte_offset + nblocks * pl.block_payload_bytes > payload)
+  if (nblocks && payload_byte_offset + (nblocks - 1) * pl.block_stride_bytes + pl.block_payload_bytes > payload)
     return fail(h, FRBCH_E_ARG, "frames do not cover the requested blocks");
   if (nblocks * pl.rows_per_block * pl.ncol * sizeof(float) > cap_bytes)
     return fail(h, FRBCH_E_CAPACITY, "power buffer too small");
@@ -858,7 +910,7 @@ extern "C" int frbch_power_device(frbch_handle* h, const void* d_frames, size_t 
     p.frame_bytes = frame_bytes;
     p.header_bytes = header_bytes;
     p.payload_bytes = frame_bytes - header_bytes;
-    p.payload_off = payload_byte_offset + b0 * pl.block_payload_bytes;
+    p.payload_off = payload_byte_offset + b0 * pl.block_stride_bytes;
     int rc = launch_front(h, p, nb, s);
     if (rc) return rc;
     p.out_mode = FRBCH_OUT_FLOAT_POWER;
@@ -923,12 +975,16 @@ int stream_begin(frbch_handle* h, const uint8_t* first_frame) {
   s0 -= s0 % spb;
   h->skip_bytes = s0 / spb;
   const double want = h->cfg.total_s * pl.rate_in;
-  h->blocks_budget = want >= 9.0e18 ? UINT64_MAX : (uint64_t)llround(want) / pl.n;
+  // blocks start every `hop` samples and read N: whole blocks inside the first -T seconds
+  const uint64_t nwant = want >= 9.0e18 ? UINT64_MAX : (uint64_t)llround(want);
+  h->blocks_budget = nwant == UINT64_MAX ? UINT64_MAX : (nwant >= pl.n ? (nwant - pl.n) / pl.hop + 1 : 0);
+  // overlap-save drops the first nfilt_pos channel samples (2C input samples each) of the stream
   h->tstart_mjd = (double)vdif_epoch_mjd((int)v.ref_epoch) +
-                  ((double)v.seconds + (double)v.frame_nr / fps + (double)s0 / pl.rate_in) / 86400.0;
+                  ((double)v.seconds + (double)v.frame_nr / fps +
+                   (double)(s0 + (uint64_t)pl.c2 * (uint64_t)pl.nfilt_pos) / pl.rate_in) / 86400.0;
   // device staging: frames of one launch batch, output of one batch (+ a completed interval)
   const uint64_t pb = v.payload_bytes();
-  const uint64_t nfr = ((uint64_t)pl.maxb * pl.block_payload_bytes + pb - 1) / pb + 2;
+  const uint64_t nfr = ((uint64_t)(pl.maxb - 1) * pl.block_stride_bytes + pl.block_payload_bytes + pb - 1) / pb + 2;
   h->d_frames_cap = nfr * v.frame_bytes;
   CHECK_DEV(h, dev_malloc((void**)&h->d_frames, h->d_frames_cap), "hipMalloc(frame staging)");
   const uint64_t burst_rows = pl.interval_rows + 2ull * pl.maxb * pl.rows_per_block;
@@ -990,9 +1046,9 @@ int process_carry(frbch_handle* h) {
     h->skip_bytes -= drop * pb;
     const uint64_t fa = frames_avail - drop;
     if (fa * pb < h->skip_bytes + pl.block_payload_bytes || h->blocks_budget == 0) break;
-    uint64_t nb = (fa * pb - h->skip_bytes) / pl.block_payload_bytes;
+    uint64_t nb = (fa * pb - h->skip_bytes - pl.block_payload_bytes) / pl.block_stride_bytes + 1;
     nb = std::min<uint64_t>(nb, std::min<uint64_t>(pl.maxb, h->blocks_budget));
-    const uint64_t need_frames = (h->skip_bytes + nb * pl.block_payload_bytes + pb - 1) / pb;
+    const uint64_t need_frames = (h->skip_bytes + (nb - 1) * pl.block_stride_bytes + pl.block_payload_bytes + pb - 1) / pb;
     const uint8_t* src = h->carry.data() + consumed_frames * fb;
     CHECK_DEV(h, dev_h2d(h->d_frames, src, need_frames * fb, h->stream), "upload frames");
     uint64_t rows = 0;
@@ -1003,7 +1059,7 @@ int process_carry(frbch_handle* h) {
     if (rc) return rc;
     if (!rows) CHECK_DEV(h, dev_sync(h->stream), "sync");
     h->blocks_budget -= nb;
-    h->skip_bytes += nb * pl.block_payload_bytes;
+    h->skip_bytes += nb * pl.block_stride_bytes;
   }
   if (consumed_frames) {
     h->carry.erase(h->carry.begin(), h->carry.begin() + consumed_frames * fb);

@@ -71,6 +71,36 @@ static int pow2_floor(uint64_t v) {
   return p;
 }
 
+std::string coherent_geometry(double freq_mhz, double bw_mhz, uint32_t nchan, uint32_t freq_res, uint32_t tscrunch,
+                              double dm, uint32_t* r_out, int* nfilt_pos, int* nfilt_neg) {
+  // worst case = the lowest-frequency channel; output sample t needs inputs t - t_hi .. t + t_lo
+  const double abw = fabs(bw_mhz), df = abw / nchan;
+  const double nu0 = (bw_mhz > 0 ? freq_mhz - abw / 2.0 + 0.5 * df                       // k = 0
+                                 : freq_mhz + abw / 2.0 - ((double)(nchan - 1) + 0.5) * df);  // k = C-1
+  if (!(nu0 - df / 2.0 > 0)) return "band reaches 0 MHz: cannot dedisperse";
+  const double d = fabs(dm) / kDmDispersion;
+  const double lo = nu0 - df / 2.0, hi = nu0 + df / 2.0;
+  const double t_lo = d * (1.0 / (lo * lo) - 1.0 / (nu0 * nu0));
+  const double t_hi = d * (1.0 / (nu0 * nu0) - 1.0 / (hi * hi));
+  const double rate = df * 1.0e6;
+  const double fpos = ceil(t_hi * rate * 1.05), fneg = ceil(t_lo * rate * 1.05);
+  if (!(fpos + fneg < 1.0e6)) return "DM smears more than freq_res can hold";
+  int pos = (int)fpos, neg = (int)fneg;
+  uint64_t r = freq_res ? freq_res : (nchan <= 128 ? 512u : 2u * nchan);
+  while (r < 4ull * (uint64_t)(pos + neg) || r < 2ull * tscrunch) r *= 2;
+  if (r > kMaxCoherentFreqRes) {
+    std::ostringstream e;
+    e << "DM " << dm << " smears " << (pos + neg) << " samples of a " << df << " MHz channel: freq_res would exceed "
+      << kMaxCoherentFreqRes;
+    return e.str();
+  }
+  neg += (int)((r - pos - neg) % tscrunch);
+  *r_out = (uint32_t)r;
+  *nfilt_pos = pos;
+  *nfilt_neg = neg;
+  return "";
+}
+
 std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int in_bits) {
   std::ostringstream e;
   if (!in_bits) in_bits = cfg.input_bits ? (int)cfg.input_bits : 2;
@@ -91,8 +121,14 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
     return e.str();
   }
   if (cfg.bw_mhz == 0.0 || !(fabs(cfg.bw_mhz) < 1.0e4)) return "BW must be non-zero";
-  if (cfg.coherent) return "coherent dedispersion (-F nchan:D) is not implemented";
   if (cfg.start_s < 0 || cfg.total_s < 0) return "-S and -T must be non-negative";
+  pl->coherent = cfg.coherent ? 1 : 0;
+  pl->nfilt_pos = pl->nfilt_neg = 0;
+  if (cfg.coherent) {   // -D <dm> -F C:D (process_vdif.py:177-180): R follows from the smearing
+    const std::string why = coherent_geometry(cfg.freq_mhz, cfg.bw_mhz, cfg.nchan, cfg.freq_res, t, cfg.dm, &r,
+                                              &pl->nfilt_pos, &pl->nfilt_neg);
+    if (!why.empty()) return why;
+  }
 
   pl->c = (int)cfg.nchan;
   pl->r = (int)r;
@@ -109,7 +145,13 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
   pl->ncol = (uint64_t)pl->nif * pl->c;
   if (pl->ncol % 4) return "nif*nchan must be divisible by 4";
   pl->block_payload_bytes = pl->n * (uint64_t)in_bits / 4;   // 2 pols x in_bits per time sample
-  pl->rows_per_block = r / t;
+  pl->keep = (int)r - pl->nfilt_pos - pl->nfilt_neg;
+  pl->hop = (uint64_t)pl->c2 * (uint64_t)pl->keep;
+  pl->block_stride_bytes = pl->hop * (uint64_t)in_bits / 4;
+  pl->rows_per_block = (uint64_t)pl->keep / t;
+  pl->k3_lds = 2 * (size_t)(r + 1) * 8;
+  pl->k4_lds = 64 * 65 * 4;
+  if (pl->coherent && pl->k3_lds > lds_limit) return "freq_res too large for the LDS of this device";
   const int nb = cfg.nbit_out < 0 ? 32 : cfg.nbit_out;
   pl->row_bytes = pl->ncol * nb / 8;
 
@@ -157,7 +199,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
   pl->fast_k2_nt = (cfg.flags & 4u) ? 1024 : 512;
   pl->k1_fast_lds = pl->k2_fast_lds = 0;
   const bool want_wave = !(cfg.flags & 8u);
-  if (!(cfg.flags & 1u) && r >= 512 && r <= 4096 && in_bits == 2) {   // the fast gather is written for 2-bit input
+  if (!(cfg.flags & 1u) && r >= 512 && r <= 4096 && in_bits == 2 && !pl->coherent) {   // the fast gather is written for 2-bit input
     const int m = (int)r / 256;
     const bool wave = want_wave && m <= 16;
     const int tps = 16 * m;
@@ -186,7 +228,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
       pl->k1_fast_lds = lds;
     }
   }
-  if (!(cfg.flags & 2u) && pl->c2 >= 512 && pl->c2 <= 4096 && pl->g >= 2) {
+  if (!(cfg.flags & 2u) && pl->c2 >= 512 && pl->c2 <= 4096 && pl->g >= 2 && !pl->coherent) {
     const int m = pl->c2 / 256;
     const bool wave = want_wave && m <= 16 && !(cfg.flags & 4u);
     const int tps = 16 * m;
@@ -218,7 +260,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
   uint32_t maxb = cfg.max_blocks_per_launch;
   if (!maxb) {
     // big batches amortise launches and let the persistent K1 run many iterations (2 GiB of spill)
-    const uint64_t spill_per_block = pl->n * 8;
+    const uint64_t spill_per_block = pl->n * 8 * (pl->coherent ? 2 : 1);
     maxb = (uint32_t)std::max<uint64_t>(1, (2048ull << 20) / spill_per_block);
     if (maxb > 256) maxb = 256;
   }

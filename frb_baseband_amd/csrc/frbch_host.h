@@ -28,7 +28,12 @@ struct Plan {
   int g, tt, tscr, nif, flip, nthreads;
   int in_bits;                // bits per input sample (2, or 1)
   uint64_t n;                 // samples per pol per block
-  uint64_t block_payload_bytes;
+  uint64_t block_payload_bytes;   // payload bytes one block reads (N samples)
+  uint64_t block_stride_bytes;    // payload bytes between block starts (= block_payload_bytes unless coherent)
+  uint64_t hop;                   // the same in samples: N, or 2C*keep
+  int coherent;                   // -F C:D pipeline
+  int nfilt_pos, nfilt_neg, keep; // overlap-save: discarded at start / end, kept (multiple of tscr); keep = R otherwise
+  size_t k3_lds, k4_lds;
   uint64_t rows_per_block;
   uint64_t row_bytes;         // bytes per output row
   uint64_t ncol;              // nif * C
@@ -52,6 +57,12 @@ struct Plan {
 
 // returns "" on success, else the reason (InputError territory)
 std::string make_plan(const frbch_config& cfg, Plan* plan, size_t lds_limit, int in_bits = 0);
+
+// overlap-save geometry of the coherent filterbank; "" on success
+std::string coherent_geometry(double freq_mhz, double bw_mhz, uint32_t nchan, uint32_t freq_res, uint32_t tscrunch,
+                              double dm, uint32_t* r, int* nfilt_pos, int* nfilt_neg);
+constexpr double kDmDispersion = 2.41e-4;   // DSPSR's constant: delay = DM / (2.41e-4 nu_MHz^2) s
+constexpr uint32_t kMaxCoherentFreqRes = 8192;
 
 std::vector<uint8_t> sigproc_header(const frbch_config& cfg, const Plan& plan, double tstart_mjd);
 double sigproc_angle(const char* text);

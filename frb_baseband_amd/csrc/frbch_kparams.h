@@ -60,6 +60,15 @@ struct KParams {
   float lut[4];             // 2-bit level table
   float digi_mean, digi_scale, digi_max;
   cf rot6[6];               // K1 remapped pass: exp(-2 pi i * step * k / R), k = 1,2,3,4,8,12, step = 64/branches per WG
+  // ---- coherent dedispersion (-F C:D): K1 forward only -> K2c chirp -> K3 inverse+detect -> K4 transpose
+  int coherent;             // 1 = that pipeline
+  int nfilt_pos;            // channel samples discarded at the start of every block (overlap-save)
+  int keep;                 // channel samples kept per block, a multiple of tscr
+  int reserved_i;
+  uint64_t hop;             // real samples between block starts: N, or 2C*keep with overlap-save
+  cf* spill2;               // [nblk][2C][R]  chirped spectrum P'[k'][j], j axis in bit-reversed position
+  const cf* chirp;          // [2C][R]        Hermitian-extended dedispersion kernel, same order
+  float* ptmp;              // [nblk][nif][C][keep/T]  detected + scrunched power, channel-major
   uint32_t nblk;            // blocks in this launch (persistent kernels loop over them)
   uint32_t dbg;             // timing-only ablations (cfg.flags >> 8); results are wrong when set
 };
@@ -86,5 +95,15 @@ struct QuantParams {
   int log2_c;
 };
 #define QUANT_GRID_X(p) ((p).grid_x)
+
+struct ChirpParams {        // frbch_chirp_build: fills KParams::chirp once per handle
+  cf* chirp;
+  int c, c2, r, log2_r;
+  int usb;                  // 1 = BW > 0
+  int reserved;
+  double band_edge_mhz;     // sky frequency of baseband 0: lower band edge (USB) / upper band edge (LSB)
+  double df_mhz;            // channel width |BW|/C
+  double dm_over_k;         // DM / 2.41e-4  [s MHz^2]
+};
 
 #endif

@@ -93,6 +93,8 @@ typedef struct frbch_info {
   uint64_t frames_seen;        /* host streaming path: frames whose header was checked           */
   uint64_t frames_invalid;     /* ... with the VDIF invalid bit set (data used as is: -cont)     */
   uint64_t frame_gaps;         /* ... frame-number discontinuities (treated as contiguous: -cont) */
+  uint64_t block_stride_bytes; /* payload bytes between block starts: = block_payload_bytes, less with -F C:D */
+  uint32_t nfilt_pos, nfilt_neg; /* -F C:D overlap-save: channel samples dropped at the start / end of a block */
 } frbch_info;
 
 /* per-kernel device time accumulated since the last frbch_timing_reset (HIP events recorded on

@@ -187,6 +187,82 @@ def filterbank_block(x: np.ndarray, nchan: int, freq_res: int) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------------------------
+# Coherent dedispersion inside the filterbank (A6 with -D <dm> -F C:D, process_vdif.py:177-180)
+#
+# DSPSR (absent, unpinned) multiplies every channel's R spectral bins by a phase-only kernel that
+# removes the cold-plasma delay RELATIVE TO THE CHANNEL CENTRE, then discards the samples at both
+# ends of each block that the cyclic convolution pollutes (overlap-save).  Restated from the
+# published algorithm (Hankins & Rickett 1975; DSPSR's dispersion constant 1/2.41e-4 s MHz^2):
+#   delay(nu) = DM / (2.41e-4 nu^2)  [s, nu in MHz]
+#   phi(fs)   = 2 pi * 1e6 * DM/2.41e-4 * fs^2 / (nu0^2 (nu0 + fs)),  fs = sky offset from centre nu0
+#   kernel    = exp(-i phi) for USB (baseband frequency rises with sky frequency), exp(+i phi) for LSB
+# Choices that DSPSR makes internally and that are OURS here (documented in DESIGN.md section 3c):
+# the guard on the smearing (5 %), R = smallest power of two >= max(rule of :162, 4 x discarded),
+# the kernel is 1 on bin (k=0, j=0) (the real-valued DC term of the band).
+# --------------------------------------------------------------------------------------------
+DM_DISPERSION = 2.41e-4          # DSPSR's dispersion constant; delay = DM / (DM_DISPERSION * nu_MHz^2) seconds
+SMEAR_GUARD = 1.05
+MAX_COHERENT_FREQ_RES = 8192
+
+
+def channel_centres_sky(freq_mhz: float, bw_mhz: float, nchan: int) -> np.ndarray:
+    """sky frequency of the centre of filterbank channel k (baseband order, before the USB flip)."""
+    df = abs(bw_mhz) / nchan
+    k = np.arange(nchan, dtype=np.float64)
+    if bw_mhz > 0:
+        return freq_mhz - abs(bw_mhz) / 2.0 + (k + 0.5) * df
+    return freq_mhz + abs(bw_mhz) / 2.0 - (k + 0.5) * df
+
+
+def smearing_samples(freq_mhz: float, bw_mhz: float, nchan: int, dm: float):
+    """(nfilt_pos, nfilt_neg): channel samples polluted at the start / at the end of a block.
+
+    Worst case = the lowest-frequency channel.  Output sample t needs inputs t - t_hi .. t + t_lo
+    (components above the centre arrived t_hi early, below it t_lo late)."""
+    df = abs(bw_mhz) / nchan
+    nu0 = channel_centres_sky(freq_mhz, bw_mhz, nchan).min()
+    d = abs(dm) / DM_DISPERSION
+    t_lo = d * (1.0 / (nu0 - df / 2.0) ** 2 - 1.0 / nu0 ** 2)
+    t_hi = d * (1.0 / nu0 ** 2 - 1.0 / (nu0 + df / 2.0) ** 2)
+    rate = df * 1.0e6
+    return int(np.ceil(t_hi * rate * SMEAR_GUARD)), int(np.ceil(t_lo * rate * SMEAR_GUARD))
+
+
+def coherent_geometry(freq_mhz: float, bw_mhz: float, nchan: int, freq_res: int, tscrunch: int, dm: float):
+    """(R, nfilt_pos, nfilt_neg, keep): keep = R - nfilt_pos - nfilt_neg is a multiple of tscrunch."""
+    pos, neg = smearing_samples(freq_mhz, bw_mhz, nchan, dm)
+    r = freq_res or freq_res_for(nchan)
+    while r < 4 * (pos + neg) or r < 2 * tscrunch:
+        r *= 2
+    if r > MAX_COHERENT_FREQ_RES:
+        raise ValueError(f"DM {dm} smears {pos + neg} samples of a {abs(bw_mhz) / nchan} MHz channel: "
+                         f"freq_res would exceed {MAX_COHERENT_FREQ_RES}")
+    neg += (r - pos - neg) % tscrunch
+    return r, pos, neg, r - pos - neg
+
+
+def chirp(freq_mhz: float, bw_mhz: float, nchan: int, freq_res: int, dm: float) -> np.ndarray:
+    """c128[nchan][freq_res] dedispersion kernel, bin j of channel k = big-spectrum bin k*R + j."""
+    df = abs(bw_mhz) / nchan
+    nu0 = channel_centres_sky(freq_mhz, bw_mhz, nchan)[:, None]
+    j = np.arange(freq_res, dtype=np.float64)[None, :]
+    fb = (j / freq_res - 0.5) * df                       # baseband offset from the channel centre
+    fs = fb if bw_mhz > 0 else -fb                       # sky offset
+    phi = 2.0 * np.pi * 1.0e6 * (dm / DM_DISPERSION) * fs * fs / (nu0 * nu0 * (nu0 + fs))
+    h = np.exp((-1j if bw_mhz > 0 else 1j) * phi)
+    h[0, 0] = 1.0
+    return h
+
+
+def filterbank_block_coherent(x: np.ndarray, nchan: int, freq_res: int, kernel: np.ndarray) -> np.ndarray:
+    """as filterbank_block with the kernel applied between the forward and the backward transforms"""
+    npol, n = x.shape
+    assert n == 2 * nchan * freq_res
+    spec = np.fft.rfft(x, axis=1)[:, : nchan * freq_res].reshape(npol, nchan, freq_res)
+    return np.fft.ifft(spec * kernel[None], axis=2) * freq_res
+
+
+# --------------------------------------------------------------------------------------------
 # Detection (A7): -P0/-P1/-d1/-d3/-d4
 # --------------------------------------------------------------------------------------------
 def nif_for(pol_mode: int) -> int:
@@ -361,6 +437,7 @@ class Config:
     rescale_constant: bool = True   # -c
     rescale_interval_s: float = DEFAULT_RESCALE_INTERVAL_S  # -I ; 0 = disabled
     dm: float = 0.0
+    coherent: bool = False          # -F C:D (process_vdif.py:177-180): dedisperse inside the filterbank
     telescope: str = "ONSALA85"
     source: str = "J0000+0000"
     ra: str = "00:00:00.0"
@@ -381,7 +458,13 @@ def detected_power(raw_frames: np.ndarray, cfg: Config):
     rate = 2.0e6 * abs(cfg.bw_mhz)                    # real samples / s / pol
     c = cfg.nchan
     r = cfg.freq_res or freq_res_for(c)
+    pos = neg = 0
+    keep = r
+    if cfg.coherent:
+        r, pos, neg, keep = coherent_geometry(cfg.freq_mhz, cfg.bw_mhz, c, cfg.freq_res, cfg.tscrunch, cfg.dm)
+        kernel = chirp(cfg.freq_mhz, cfg.bw_mhz, c, r, cfg.dm)
     n = 2 * c * r
+    hop = 2 * c * keep                                # overlap-save: blocks advance by the kept samples
     bits = hdr.bits_per_sample
     spb = 4 // bits                                   # dual-pol time samples per payload byte
     s0 = int(round(cfg.start_s * rate))
@@ -389,15 +472,20 @@ def detected_power(raw_frames: np.ndarray, cfg: Config):
     navail = payload.size * spb - s0
     nwant = int(round(cfg.total_s * rate))
     nsamp = max(0, min(navail, nwant))
-    nblocks = nsamp // n
-    x = unpack(payload[s0 // spb: s0 // spb + nblocks * n // spb], bits)
+    nblocks = (nsamp - n) // hop + 1 if nsamp >= n else 0
+    x = unpack(payload[s0 // spb: s0 // spb + ((nblocks - 1) * hop + n) // spb if nblocks else s0 // spb], bits)
     out = []
     for b in range(nblocks):
-        y = filterbank_block(x[:, b * n:(b + 1) * n], c, r)
+        xb = x[:, b * hop: b * hop + n]
+        if cfg.coherent:
+            y = filterbank_block_coherent(xb, c, r, kernel)[:, :, pos: r - neg]
+        else:
+            y = filterbank_block(xb, c, r)
         out.append(detect(y, cfg.pol_mode))
     nif = nif_for(cfg.pol_mode)
     p = np.concatenate(out, axis=2) if out else np.zeros((nif, c, 0))
-    return tscrunch(p, cfg.tscrunch), hdr, s0, r
+    cfg.result["geometry"] = (r, pos, neg, keep)
+    return tscrunch(p, cfg.tscrunch), hdr, s0 + 2 * c * pos, r
 
 
 def channelise(raw_frames: np.ndarray, cfg: Config) -> bytes:

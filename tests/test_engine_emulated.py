@@ -29,6 +29,12 @@ CASES = [
     (-16.0, 64, 0.03, dict(pol=4, bits=1, start=0.01 + 2 / 32e6)),  # 1 bit, LSB, -S not on a byte boundary
     (16.0, 32, 0.03, dict(freq_res=64, payload_bytes=10000)), # Mark5B-sized payload (spif2file.sh mode table)
     (16.0, 32, 0.03, dict(freq_res=64, payload_bytes=1000, legacy=1, bits=1)),
+    # coherent dedispersion -D <dm> -F C:D (process_vdif.py:177-180): overlap-save blocks, K1 -> K2c -> K3 -> K4
+    (16.0, 16, 0.012, dict(dm=1.0, coherent=1, freq=316.0)),
+    (-16.0, 16, 0.012, dict(dm=1.0, coherent=1, freq=316.0, pol=4, tscr=2, maxb=2)),
+    (16.0, 16, 0.012, dict(dm=1.0, coherent=1, freq=316.0, pol=3, nbit=2, tscr=8, interval=0.004, const=0)),
+    (-16.0, 32, 0.012, dict(dm=0.7, coherent=1, freq=330.0, nbit=-32, start=0.001, bits=1)),
+    (16.0, 64, 0.02, dict(dm=56.7, coherent=1, freq=1400.0, nbit=16, freq_res=128)),   # tiny smearing: 1 + 1 samples
 ]
 
 
@@ -117,7 +123,9 @@ def test_rejects_unsupported_streams(emu_lib):
     with ch.Channeliser(pu.lib_cfg(emu_lib, 16.0, 32, 1.0, freq_res=64), emu_lib) as c:
         with pytest.raises(ch.RunError):
             c.push(raw)
-    for bad in (dict(nchan=100), dict(tscrunch=3), dict(nbit_out=4), dict(pol_mode=7), dict(coherent=1),
+    for bad in (dict(nchan=100), dict(tscrunch=3), dict(nbit_out=4), dict(pol_mode=7),
+                dict(coherent=1, dm=5000.0, freq_mhz=300.0, nchan=16),      # smearing beyond the largest freq_res
+               
                 dict(bw_mhz=0.0), dict(nchan=32, freq_res=64, tscrunch=128)):
         with pytest.raises(ch.InputError):
             ch.Channeliser(ch.new_config(emu_lib, **bad), emu_lib)

@@ -49,6 +49,11 @@ CASES = [
     (32.0, 1024, 0.2, dict(bits=1, pol=4, tscr=2)),          # 1-bit mode VDIF_8000-1024-16-1: generic K1 gather feeds the fast K2
     (-16.0, 128, 0.05, dict(bits=1, start=0.0101)),
     (32.0, 1024, 0.2, dict(payload_bytes=10000)),            # Mark5B-sized payload through the fast kernels
+    # coherent dedispersion (-D <dm> -F C:D, process_vdif.py:177-180): K1 forward -> K2c chirp -> K3 -> K4
+    (16.0, 16, 0.012, dict(dm=1.0, coherent=1, freq=316.0)),
+    (-32.0, 1024, 0.3, dict(dm=56.7, coherent=1, freq=400.0, tscr=4)),
+    (-32.0, 512, 0.15, dict(dm=26.7, coherent=1, freq=350.0, pol=4, tscr=2, nbit=16)),
+    (32.0, 2048, 0.6, dict(dm=56.7, coherent=1, freq=1400.0, freq_res=4096)),   # BASELINE config 5 shape: -F2048:4096 -D 56.7 -F2048:D
     (64.0, 4096, 1.1, dict(tscr=8)),                         # BASELINE config 4 shape (-t 8 -F4096:8192): generic kernels, 2 blocks
 ]
 
