@@ -118,6 +118,26 @@ def test_digifil_shim_into_fifo(tmp_path):
         pv.run_digifil(str(tmp_path / "missing.hdr"), str(tmp_path), 0, 1, 1024, overwrite=True, backend="shim")
 
 
+def test_known_pulsar_flags_through_the_harness(tmp_path):
+    """process_vdif.py:177-180: `-D <dm> -F<C>:D` appended after `-F<C>:<R>` (last wins) -> coherent filterbank,
+    in-process through the C-ABI; refdm lands in the SIGPROC header."""
+    raw = synth.make_vdif(0.3, bw_mhz=32.0, nchan=1024)
+    vd = str(tmp_path / "pr001a_ef_no0002_IF1.vdif")
+    raw.tofile(vd)
+    hdr = pv.make_hdr("B0329+54", 420.0, vd, pol=2, usb=True, ra="03:32:59.4", dec="54:34:43.3", bw=32.0,
+                      telescope="effelsberg")
+    with contextlib.redirect_stdout(io.StringIO()) as log:
+        fil = pv.run_digifil(hdr, str(tmp_path), 0, 0.3, 1024, overwrite=True, pol=2, nbit=8, tscrunch=4, dm=26.7,
+                             coherent=True)
+    assert "-D 26.7 -F1024:D" in log.getvalue()
+    got = open(fil, "rb").read()
+    ocfg = o.config_from_hdr(hdr, nchan=1024, total_s=0.3, tscrunch=4, dm=26.7, coherent=True)
+    pu.check_codes(o.channelise(raw, ocfg), got, ocfg)
+    r, pos, neg, keep = ocfg.result["geometry"]
+    assert r == 2048 and pos > 0 and neg > 0 and keep % 4 == 0
+    assert sigproc.read_fil(got).header["refdm"] == 26.7
+
+
 def test_multi_if_scan_on_device(tmp_path):
     d = str(tmp_path)
     raws, vd = {}, {}
