@@ -83,8 +83,22 @@ def cpu_baseline(seconds_budget: float, bw: float, nchan: int):
             c_oracle.channelise_blocks(raw, bw, nchan, r, 2)
             nblk += 2
         dt = time.perf_counter() - t0
-        return {"value": nblk * n / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
-                "sample": f"{nblk} filterbank blocks of {n} dual-pol samples, C fp32 port (oracle/frb_oracle.c), 1 thread"}
+        res = {"value": nblk * n / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+               "sample": f"{nblk} filterbank blocks of {n} dual-pol samples, C fp32 port (oracle/frb_oracle.c), 1 thread"}
+        # all host cores, the way the reference fans out: one single-threaded process per IF (base2fil.sh:60-66,219).
+        # Child processes never touch the GPU.
+        try:
+            import subprocess
+            ncpu = len(os.sched_getaffinity(0))
+            procs = [subprocess.Popen([sys.executable, "-m", "oracle.c_oracle", str(seconds_budget / 2), str(bw), str(nchan), str(i)],
+                                      cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+                     for i in range(ncpu)]
+            rates = [float(pr.communicate(timeout=seconds_budget * 4 + 120)[0].strip().splitlines()[-1]) for pr in procs]
+            res["all_cores"] = {"value": sum(rates) / 1e6, "unit": "Msamples/s", "cores": ncpu,
+                                "sample": f"{ncpu} single-threaded processes, one IF each, {seconds_budget / 2:g} s"}
+        except Exception as exc:   # reported baseline only: never fail the bench for it
+            res["all_cores"] = {"error": str(exc)}
+        return res
     cfg = o.Config(bw_mhz=bw, nchan=nchan, total_s=10.0)
     t0 = time.perf_counter()
     nblk = 0

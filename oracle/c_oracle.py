@@ -57,3 +57,24 @@ def channelise_blocks(raw_frames: np.ndarray, bw: float, nchan: int, freq_res: i
     fb = 8032
     payload = raw_frames[: raw_frames.size // fb * fb].reshape(-1, fb)[:, 32:].reshape(-1)
     return block_power(payload, nchan, freq_res, nblocks)
+
+
+def _bench_worker(seconds: float, bw: float, nchan: int, seed: int = 0) -> float:
+    """one `digifil_nthreads=1` process of the reference's per-IF fan-out (base2fil.sh:60-66,219): blocks/s"""
+    import time
+    from frb_baseband_amd import synth
+    from oracle import frb_oracle as o
+    r = o.freq_res_for(nchan)
+    n = 2 * nchan * r
+    raw = synth.make_vdif(2 * n / (2e6 * bw) + 0.001, bw_mhz=bw, nchan=nchan, if_index=seed)
+    t0 = time.perf_counter()
+    nblk = 0
+    while time.perf_counter() - t0 < seconds:
+        channelise_blocks(raw, bw, nchan, r, 2)
+        nblk += 2
+    return nblk * n / (time.perf_counter() - t0)
+
+
+if __name__ == "__main__":   # python -m oracle.c_oracle <seconds> <bw> <nchan> <seed>: prints samples/s (bench.py's all-cores leg)
+    import sys
+    print(_bench_worker(float(sys.argv[1]), float(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])))
