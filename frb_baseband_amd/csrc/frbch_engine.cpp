@@ -242,7 +242,12 @@ template <int LOG2M>
 void launch_k2_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s, uint32_t h_flags) {
   const int tps = 16 << LOG2M;
   const int spw = tps < 64 ? 64 / tps : 1;
-  const dim3 grid2(pl.r / (2 * spw), nb), grid4(pl.r / (4 * spw), nb), grid8(pl.r / (8 * spw), nb);
+  // persistent: one wave of workgroups loops over the (tiles per block) x nb tiles of the launch
+  p.nblk = nb;
+  static const uint32_t npers_env = getenv("FRBCH_K2_NPERS") ? (uint32_t)atoi(getenv("FRBCH_K2_NPERS")) : 0u;   // experiments
+  const uint32_t npers = npers_env ? npers_env : 8192u;   // measured: 768 (= resident) 1.59 ms, 2048 1.56, 8192 1.49 (shorter tail)
+  auto pers = [&](uint32_t tiles_per_block) { return dim3(std::min<uint64_t>((uint64_t)tiles_per_block * nb, npers)); };
+  const dim3 grid2 = pers(pl.r / (2 * spw)), grid4 = pers(pl.r / (4 * spw)), grid8 = pers(pl.r / (8 * spw));
   const int pm = p.pol_mode == 2 ? 2 : (p.pol_mode == 4 ? 4 : 0);
 #define FRBCH_K2W(NWV, PMV, GRID) hipLaunchKernelGGL((fast::frbch_k2_wave<LOG2M, NWV, PMV>), GRID, dim3(64 * NWV), pl.k2_fast_lds, s, p)
   if constexpr (LOG2M == 4) {   // 2C = 4096: two waves per sequence; 2 or 4 sequences per workgroup
