@@ -6,8 +6,7 @@ import json
 d=json.loads(open("gpurun_out/abl_$1.json").read().strip().splitlines()[-1]); print("$1", d["value"], d["config"]["steady_state_msamples_per_gpu"], d["roofline"]["kernels_ms_per_step"])
 PY
 }
-run base A=1 0
-run nostore A=1 512
-run c2048 A=1 0 "--nchan 2048"
-run c512 A=1 0 "--nchan 512"
-run c256 A=1 0 "--nchan 256"
+run k1half_s0 FRBCH_K1_STAG=0 192
+run k1half_s3 FRBCH_K1_STAG=3 192
+run k1half_s6 FRBCH_K1_STAG=6 192
+run k1two_s3 FRBCH_K1_STAG=3 64

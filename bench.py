@@ -89,7 +89,8 @@ def cpu_baseline(seconds_budget: float, bw: float, nchan: int):
         # Child processes never touch the GPU.
         try:
             import subprocess
-            ncpu = len(os.sched_getaffinity(0))
+            # the GPU box gives a one-GPU job a share of 16 host cores: do not take more
+            ncpu = min(len(os.sched_getaffinity(0)), int(os.environ.get("FRBCH_CPU_WORKERS", "16")))
             procs = [subprocess.Popen([sys.executable, "-m", "oracle.c_oracle", str(seconds_budget / 2), str(bw), str(nchan), str(i)],
                                       cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
                      for i in range(ncpu)]
