@@ -3,10 +3,7 @@ run() { # label, env, flags, extra
   env $2 timeout -k 10 200 python bench.py --steps 3 --warmup 1 --no-cpu --flags $3 $4 > gpurun_out/abl_$1.json 2>gpurun_out/abl_$1.err || exit 1
   python - <<PY
 import json
-d=json.loads(open("gpurun_out/abl_$1.json").read().strip().splitlines()[-1]); print("$1", d["value"], d["config"]["steady_state_msamples_per_gpu"], d["roofline"]["kernels_ms_per_step"])
+d=json.loads(open("gpurun_out/abl_$1.json").read().strip().splitlines()[-1]); k=d["roofline"]["kernels_ms_per_step"]; print("$1", d["value"], d["config"]["steady_state_msamples_per_gpu"], [round(v,3) for v in list(k.values())[:5]])
 PY
 }
-run k1half_s0 FRBCH_K1_STAG=0 192
-run k1half_s3 FRBCH_K1_STAG=3 192
-run k1half_s6 FRBCH_K1_STAG=6 192
-run k1two_s3 FRBCH_K1_STAG=3 64
+for p in 16 48 96 160 272 400 1040 1296 4112 8208; do run pad$p FRBCH_SPILL_PAD=$p 0; done

@@ -171,6 +171,7 @@ KParams base_params(const frbch_handle* h) {
   p.log2_nlo = pl.log2_nlo;
   p.in_bits = pl.in_bits;
   p.spill = h->spill;
+  p.gs = pl.gs;
   p.s_dc = h->s_dc;
   p.p0 = h->p0;
   p.tw_r = h->tw_r;
@@ -762,7 +763,7 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
     }
   }
 
-  CHECK_DEV(h, dev_malloc((void**)&h->spill, (size_t)pl.maxb * pl.n * sizeof(cf)), "hipMalloc(spill)");
+  CHECK_DEV(h, dev_malloc((void**)&h->spill, (size_t)pl.maxb * (pl.c2 / pl.g) * pl.gs * sizeof(cf)), "hipMalloc(spill)");
   CHECK_DEV(h, dev_malloc((void**)&h->s_dc, (size_t)pl.maxb * pl.c2 * sizeof(cf)), "hipMalloc(s_dc)");
   CHECK_DEV(h, dev_malloc((void**)&h->p0, (size_t)pl.maxb * pl.c2 * sizeof(cf)), "hipMalloc(p0)");
   if (pl.coherent) {
@@ -975,6 +976,9 @@ int stream_begin(frbch_handle* h, const uint8_t* first_frame) {
     CHECK_DEV(h, dev_allow_lds(frbch_k1_branch, h->pl.k1_lds), "LDS size K1");
     CHECK_DEV(h, dev_allow_lds(frbch_k2_chan, h->pl.k2_lds), "LDS size K2");
     h->kname[KID_K1].clear();
+    dev_free(h->spill);   // the group size (hence the padded slab count) may have changed
+    h->spill = nullptr;
+    CHECK_DEV(h, dev_malloc((void**)&h->spill, (size_t)h->pl.maxb * (h->pl.c2 / h->pl.g) * h->pl.gs * sizeof(cf)), "hipMalloc(spill)");
   }
   const Plan& pl = h->pl;
   const uint64_t spb = 4 / (uint64_t)pl.in_bits;                       // dual-pol samples per payload byte

@@ -267,6 +267,12 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
   if (maxb > 32768) maxb = 32768;
   while (maxb > 1 && (uint64_t)maxb * pl->block_payload_bytes > (1ull << 31)) maxb /= 2;  // 32-bit launch-relative offsets
   pl->maxb = maxb;
+  // Spill slabs of one block are R*g*8 B = a power of two apart: the 2C/g pieces K2 gathers for one tile would
+  // all sit on one HBM channel.  A pad per slab spreads them.
+  static const int pad_env = getenv("FRBCH_SPILL_PAD") ? atoi(getenv("FRBCH_SPILL_PAD")) : -1;   // experiments, in cf
+  // measured (K2, cfg 2): pad 0 -> 1.55 ms, 16 -> 1.38, 48..8208 -> 1.29-1.33; 272 cf = 2 KB + 128 B
+  const int pad = (uint64_t)pl->r * pl->g >= 2048 ? 272 : 16;
+  pl->gs = (uint64_t)pl->r * pl->g + (uint64_t)(pad_env >= 0 ? pad_env : pad);
   return "";
 }
 

@@ -28,6 +28,7 @@ struct Plan {
   int g, tt, tscr, nif, flip, nthreads;
   int in_bits;                // bits per input sample (2, or 1)
   uint64_t n;                 // samples per pol per block
+  uint64_t gs;                    // spill group stride in cf (R*g + pad)
   uint64_t block_payload_bytes;   // payload bytes one block reads (N samples)
   uint64_t block_stride_bytes;    // payload bytes between block starts (= block_payload_bytes unless coherent)
   uint64_t hop;                   // the same in samples: N, or 2C*keep

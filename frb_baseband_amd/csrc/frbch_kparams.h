@@ -37,7 +37,8 @@ struct KParams {
   uint64_t payload_off;     // payload byte at which block 0 of this launch starts
   const uint8_t* frames;
   // ---- work buffers -------------------------------------------------------------------------
-  cf* spill;                // [nblk][2C/g][R][g]   delayed branch series w[n1][t]
+  uint64_t gs;              // group stride of the spill in cf: R*g + pad (pad keeps the 2C/g slabs off one HBM channel)
+  cf* spill;                // [nblk][2C/g][gs >= R*g]: rows [t][g] of the delayed branch series w[n1][t]
   cf* s_dc;                 // [nblk][2C]           S[n1] = sum_n2 p[n1 + 2C n2]
   cf* p0;                   // [nblk][2C]           dP[k'] = P[(k'+1)R] - P[k'R], P[k'R] = FFT_2C(S)
   const cf* tw_r;           // exp(-2 pi i k / R),  k < R/2
