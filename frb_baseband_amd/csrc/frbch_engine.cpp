@@ -67,6 +67,10 @@ struct frbch_handle {
   uint64_t pow_cap_rows = 0, pow_rows = 0;
   double* partial = nullptr;
   int partial_chunks = 0;
+  // rescale statistics accumulated by the fast K2 while it emits the float power (no second pass)
+  uint64_t fused_rows = 0;     // rows of the current interval whose moments are in `partial`
+  bool fused_valid = false;    // ... and no row of the interval is missing from them
+  int fused_chunks = 0;        // rows of `partial` the fused path uses (0 = this configuration cannot fuse)
 
   uint64_t rows_out = 0, blocks_done = 0;
 
@@ -193,7 +197,7 @@ KParams base_params(const frbch_handle* h) {
   p.digi_mean = pl.digi_mean;
   p.digi_scale = pl.digi_scale;
   p.digi_max = pl.digi_max;
-  p.dbg = h->cfg.flags >> 8;
+  p.dbg = (h->cfg.flags >> 8) & 0xFFFu;   // bits 8..19; bit 20 selects the separate statistics pass
   p.coherent = pl.coherent;
   p.nfilt_pos = pl.nfilt_pos;
   p.keep = pl.keep;
@@ -242,14 +246,31 @@ void launch_k1_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
       hipLaunchKernelGGL((fast::frbch_k1_wave<LOG2M, 8, 1>), dim3(ngrp, ny), dim3(512), pl.k1_fast_lds, s, p);
   }
 }
+constexpr uint32_t kFusedStatWgs = 2048;   // persistent K2 workgroups (= rows of partial sums per thread row) while statistics are fused
+// threads per workgroup of the wave-private K2 variant launch_k2_wave_t selects
+int k2_wave_nt(const Plan& pl, uint32_t h_flags) {
+  if (pl.fast_k2_log2m == 4) return pl.fast_k2_nw == 2 ? 256 : 512;
+  if (pl.fast_k2_nw == 8) return 512;
+  if (pl.fast_k2_log2m == 3 && !(h_flags & 32u)) return pl.fast_k2_nw == 2 ? 256 : 512;
+  return pl.fast_k2_nw == 2 ? 128 : 256;
+}
+// rows of partial sums the fused statistics use; 0 = this configuration cannot fuse (one column group per thread needed)
+int fused_stat_chunks(const Plan& pl, uint32_t h_flags, int pol_mode) {
+  if (pol_mode == 3) return 0;   // (PP+QQ)^2: its square overflows the fp32 partial sums (~1e24 squared)
+  if (!pl.fast_k2_log2m || !pl.fast_k2_wave || pl.coherent || (h_flags & (1u << 20))) return 0;
+  const int nt = k2_wave_nt(pl, h_flags), cg = (int)(pl.ncol / 4);
+  if (!(cg <= nt && nt % cg == 0)) return 0;
+  return (int)kFusedStatWgs * (nt / cg);
+}
 template <int LOG2M>
 void launch_k2_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s, uint32_t h_flags) {
   const int tps = 16 << LOG2M;
   const int spw = tps < 64 ? 64 / tps : 1;
   // persistent: one wave of workgroups loops over the (tiles per block) x nb tiles of the launch
   p.nblk = nb;
+  if (!fused_stat_chunks(pl, h_flags, p.pol_mode)) p.stat_partial = nullptr;
   static const uint32_t npers_env = getenv("FRBCH_K2_NPERS") ? (uint32_t)atoi(getenv("FRBCH_K2_NPERS")) : 0u;   // experiments
-  const uint32_t npers = npers_env ? npers_env : 8192u;   // measured: 768 (= resident) 1.59 ms, 2048 1.56, 8192 1.49 (shorter tail)
+  const uint32_t npers = p.stat_partial ? kFusedStatWgs : (npers_env ? npers_env : 8192u);   // measured: 768 (= resident) 1.59 ms, 2048 1.56, 8192 1.49 (shorter tail)
   auto pers = [&](uint32_t tiles_per_block) { return dim3(std::min<uint64_t>((uint64_t)tiles_per_block * nb, npers)); };
   const dim3 grid2 = pers(pl.r / (2 * spw)), grid4 = pers(pl.r / (4 * spw)), grid8 = pers(pl.r / (8 * spw));
   const int pm = p.pol_mode == 2 ? 2 : (p.pol_mode == 4 ? 4 : 0);
@@ -520,6 +541,7 @@ int launch_back(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   const int tile_t = std::max(pl.tt, pl.tscr);
   const double out_b = p.out_mode == FRBCH_OUT_FLOAT_POWER ? (double)pl.ncol * 4.0 : (double)pl.row_bytes;
   const double bytes = (double)nb * ((double)pl.n * 8.0 + (double)pl.rows_per_block * out_b);
+  if (!(pl.fast_k2_log2m && pl.fast_k2_wave) || pl.coherent) p.stat_partial = nullptr;   // only the wave-private K2 sums while it writes
   if (pl.coherent) {   // K2c (branches -> channels, x kernel), K3 (back to time, detect), K4 (time-major rows)
     {
       ProfScope ps(h, s, KID_K2, (double)nb * (double)pl.n * 24.0);
@@ -550,7 +572,12 @@ int ensure_powbuf(frbch_handle* h) {
   h->pow_cap_rows = pl.interval_rows + (uint64_t)pl.maxb * pl.rows_per_block;
   CHECK_DEV(h, dev_malloc((void**)&h->powbuf, h->pow_cap_rows * pl.ncol * sizeof(float)), "hipMalloc(power buffer)");
   h->partial_chunks = 2048;
-  CHECK_DEV(h, dev_malloc((void**)&h->partial, (size_t)h->partial_chunks * pl.ncol * 2 * sizeof(double)), "hipMalloc(partials)");
+  h->fused_chunks = 0;
+#ifndef FRBCH_NO_FAST
+  h->fused_chunks = fused_stat_chunks(pl, h->cfg.flags, h->cfg.pol_mode);   // flag bit 20 forces the separate statistics pass
+#endif
+  const size_t chunks = (size_t)std::max(h->partial_chunks, h->fused_chunks);
+  CHECK_DEV(h, dev_malloc((void**)&h->partial, chunks * pl.ncol * 2 * sizeof(double)), "hipMalloc(partials)");
   return FRBCH_OK;
 }
 
@@ -558,6 +585,21 @@ int run_stats(frbch_handle* h, uint64_t rows, dev_stream_t s) {
   const Plan& pl = h->pl;
   StatParams sp;
   memset(&sp, 0, sizeof sp);
+  if (h->fused_valid && h->fused_chunks && h->fused_rows == rows) {   // K2 already summed these rows: reduce only
+    sp.partial = h->partial;
+    sp.rows = rows;
+    sp.ncol = (int)pl.ncol;
+    sp.c = pl.c;
+    sp.nif = pl.nif;
+    sp.flip = pl.flip;
+    sp.nchunk = h->fused_chunks;
+    sp.offset = h->offset;
+    sp.scale = h->scale;
+    ProfScope ps(h, s, KID_STATS, (double)h->fused_chunks * pl.ncol * 16.0);
+    DEV_LAUNCH(frbch_stats_final, (int)pl.ncol, 1, 64, 64 * 2 * sizeof(double), s, sp);
+    CHECK_DEV(h, dev_check_launch(), "launch stats (final)");
+    return FRBCH_OK;
+  }
   sp.power = h->powbuf;
   sp.partial = h->partial;
   sp.rows = rows;
@@ -634,6 +676,8 @@ int finalize_interval(frbch_handle* h, uint64_t stat_rows, uint8_t* d_out, size_
     done += len;
   }
   h->pow_rows = rest;
+  h->fused_rows = 0;
+  h->fused_valid = false;   // (re-armed when an interval starts on an empty buffer)
   return FRBCH_OK;
 }
 
@@ -673,8 +717,25 @@ int engine_feed(frbch_handle* h, const uint8_t* d_frames, uint32_t frame_bytes, 
       p.out_mode = FRBCH_OUT_FLOAT_POWER;
       p.power_out = h->powbuf;
       p.row0 = h->pow_rows;
+      if (h->pow_rows == 0 && h->fused_chunks) {   // an interval starts here: K2 can sum it while writing it
+        CHECK_DEV(h, dev_memset(h->partial, 0, (size_t)h->fused_chunks * pl.ncol * 2 * sizeof(double), s), "clear partial sums");
+        h->fused_rows = 0;
+        h->fused_valid = true;
+      }
+      if (h->fused_valid) {
+        p.stat_partial = h->partial;
+        p.stat_limit = pl.interval_rows;
+      }
       rc = launch_back(h, p, nb, s);
       if (rc) return rc;
+      if (h->fused_valid) {
+        if (p.stat_partial) {
+          const uint64_t room = pl.interval_rows > h->pow_rows ? pl.interval_rows - h->pow_rows : 0;
+          h->fused_rows += std::min<uint64_t>(rows, room);
+        } else {
+          h->fused_valid = false;   // this launch ran a kernel that does not accumulate
+        }
+      }
       h->pow_rows += rows;
       while (!fused_ok(h) && h->pow_rows >= pl.interval_rows) {
         rc = finalize_interval(h, pl.interval_rows, d_out, cap, rows_written, s);
@@ -844,6 +905,8 @@ extern "C" int frbch_reset(frbch_handle* h) {
   if (!h) return FRBCH_E_ARG;
   CHECK_DEV(h, dev_sync(h->stream), "sync");
   h->pow_rows = 0;
+  h->fused_rows = 0;
+  h->fused_valid = false;
   h->rows_out = h->blocks_done = 0;
   h->have_vdif = false;
   h->frames_seen = h->frames_invalid = h->frame_gaps = 0;

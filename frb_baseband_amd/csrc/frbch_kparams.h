@@ -70,6 +70,8 @@ struct KParams {
   cf* spill2;               // [nblk][2C][R]  chirped spectrum P'[k'][j], j axis in bit-reversed position
   const cf* chirp;          // [2C][R]        Hermitian-extended dedispersion kernel, same order
   float* ptmp;              // [nblk][nif][C][keep/T]  detected + scrunched power, channel-major
+  double* stat_partial;     // fast K2, float power: [workgroup row][ncol][2] running (sum, sum of squares); null = off
+  uint64_t stat_limit;      // ... of the rows below this absolute row of power_out (the end of the rescale interval)
   uint32_t nblk;            // blocks in this launch (persistent kernels loop over them)
   uint32_t dbg;             // timing-only ablations (cfg.flags >> 8); results are wrong when set
 };

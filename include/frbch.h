@@ -54,12 +54,13 @@ typedef struct frbch_config {
   uint32_t rescale_constant;   /* -c (always passed, process_vdif.py:157,160)                 */
   double rescale_interval_s;   /* -I secs; 0 = -I0 = keepBP (process_vdif.py:181-182)         */
   double dm;                   /* -D (last one wins; header refdm; process_vdif.py:177-178)   */
-  uint32_t coherent;           /* -F<nchan>:D (process_vdif.py:179-180); not implemented yet  */
+  uint32_t coherent;           /* -F<nchan>:D (process_vdif.py:179-180): dedisperse in the filterbank */
   int32_t device;              /* GPU ordinal (>= 0)                                          */
   uint32_t max_blocks_per_launch; /* 0 = auto; filterbank blocks batched per kernel launch    */
   uint32_t flags;              /* 0 in production.  Kernel-selection switches for A/B measurements: 1 generic K1,
                                 * 2 generic K2, 4 1024-thread K2, 8 barrier (non wave-private) kernels, 16 4-sequence K2,
-                                * 32 one wave per sequence in K2, 64/128 experimental K1 shapes; bits >= 8 (flags >> 8)
+                                * 32 one wave per sequence in K2, 64/128 experimental K1 shapes, 1<<20 rescale statistics in a
+                                * separate pass over the power buffer instead of inside K2; bits 8..19 (flags >> 8)
                                 * are timing-only ablations that produce WRONG output (used by the profiling notes)   */
   char telescope[64];          /* .hdr TELESCOPE  (process_vdif.py:123)                       */
   char source[64];             /* .hdr SOURCE     (:124)                                      */

@@ -87,6 +87,32 @@ def test_full_size_is_deterministic_and_rescale_is_reusable(hip_lib, ten_seconds
     assert abs(d.mean() - 127.5) < 0.6 and abs(d.std() - 127.5 / 6) < 1.5
 
 
+def test_statistics_summed_by_k2_equal_the_separate_pass(hip_lib, ten_seconds):
+    """A9 fused into K2 (fp32 partial sums per workgroup, fp64 across workgroups) against the separate fp64 pass over
+    the power buffer (flag bit 20), for an interval that is the whole file and for one that ends inside a block."""
+    raw = ten_seconds[: 8032 * 4000 * 2]                      # 2 s
+    d_raw = DeviceBuffer.from_numpy(raw)
+    nfr = raw.size // 8032
+    for interval in (10.0, 0.7):
+        res = []
+        for flags in (0, 1 << 20):
+            cfg = pu.lib_cfg(hip_lib, 32.0, 1024, 2.0, interval=interval, flags=flags)
+            with ch.Channeliser(cfg, hip_lib) as c:
+                info = c.info
+                nblocks = (nfr * 8000) // info.block_payload_bytes
+                out = DeviceBuffer(nblocks * info.rows_per_block * info.row_bytes)
+                r1 = c.process_device(d_raw.ptr.value, nfr, 8032, 32, 0, nblocks, out.ptr.value, out.nbytes)
+                r2 = c.flush_device(out.ptr.value + r1 * info.row_bytes, out.nbytes - r1 * info.row_bytes)
+                assert r1 + r2 == nblocks * info.rows_per_block
+                res.append((c.get_rescale(), out.to_numpy(np.uint8)))
+        (off_a, sc_a), codes_a = res[0]
+        (off_b, sc_b), codes_b = res[1]
+        assert np.abs(off_a - off_b).max() <= 2e-7 * np.abs(off_b).max()
+        np.testing.assert_allclose(sc_a, sc_b, rtol=1e-6)
+        diff = codes_a.astype(np.int16) - codes_b.astype(np.int16)
+        assert np.abs(diff).max() <= 1 and np.count_nonzero(diff) < 1e-4 * diff.size
+
+
 def test_digifil_shim_into_fifo(tmp_path):
     """the flag-compatible `digifil` executable, driven through the harness mirror, writing into a pre-made FIFO
     (base2fil.sh:348-349), read concurrently like `splice` would."""
