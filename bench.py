@@ -114,8 +114,9 @@ def cpu_baseline(seconds_budget: float, bw: float, nchan: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=10,
+                    help="untimed steps; the first steps on a fresh box run ~5 %% slower (clock / power state settle)")
     ap.add_argument("--seconds", type=float, default=10.0, help="seconds of one IF per step (SURVEY 8d: 10 s)")
     ap.add_argument("--nchan", type=int, default=1024)
     ap.add_argument("--bw", type=float, default=32.0)

@@ -227,8 +227,6 @@ void launch_k1_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
       p.rot6[i].y = (float)sin(a);
     }
   }
-  static const int stag_env = getenv("FRBCH_K1_STAG") ? atoi(getenv("FRBCH_K1_STAG")) : -1;   // experiments
-  p.k1_stagger = stag_env >= 0 ? stag_env : 3;   // measured (K1, cfg 2): 0 -> 2.14 ms, 2 -> 1.96, 3 -> 1.93, 5 -> 1.95
   const uint32_t ngrp = (uint32_t)(pl.c2 / kg);
   static const uint32_t cap_env = getenv("FRBCH_K1_MAXWG") ? (uint32_t)atoi(getenv("FRBCH_K1_MAXWG")) : 0u;   // experiments
   const uint32_t resident = cap_env ? cap_env : 256u * (uint32_t)std::max<size_t>(1, (160 * 1024) / pl.k1_fast_lds);

@@ -65,7 +65,7 @@ struct KParams {
   int coherent;             // 1 = that pipeline
   int nfilt_pos;            // channel samples discarded at the start of every block (overlap-save)
   int keep;                 // channel samples kept per block, a multiple of tscr
-  int k1_stagger;           // persistent K1: start delay per phase step (16 steps), in units of 1024 clocks; 0 = off
+  int reserved_i;
   uint64_t hop;             // real samples between block starts: N, or 2C*keep with overlap-save
   cf* spill2;               // [nblk][2C][R]  chirped spectrum P'[k'][j], j axis in bit-reversed position
   const cf* chirp;          // [2C][R]        Hermitian-extended dedispersion kernel, same order
