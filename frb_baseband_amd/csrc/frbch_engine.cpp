@@ -316,10 +316,12 @@ void set_fastdiv(KParams& p) {
 template <int LOG2M>
 void launch_k2_fast_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
   const int tps = 16 << LOG2M;
+  // time samples per workgroup: its TT-sample tile, or (M = 32 only) tscrunch/TT tiles in a row
+  const int tile_t = std::max(pl.fast_k2_nt / tps, pl.tscr);
   if (pl.fast_k2_nt == 1024)
-    hipLaunchKernelGGL((fast::frbch_k2_fast<LOG2M, 1024>), dim3(pl.r / (1024 / tps), nb), dim3(1024), pl.k2_fast_lds, s, p);
+    hipLaunchKernelGGL((fast::frbch_k2_fast<LOG2M, 1024>), dim3(pl.r / tile_t, nb), dim3(1024), pl.k2_fast_lds, s, p);
   else
-    hipLaunchKernelGGL((fast::frbch_k2_fast<LOG2M, 512>), dim3(pl.r / (512 / tps), nb), dim3(512), pl.k2_fast_lds, s, p);
+    hipLaunchKernelGGL((fast::frbch_k2_fast<LOG2M, 512>), dim3(pl.r / tile_t, nb), dim3(512), pl.k2_fast_lds, s, p);
 }
 template <int LOG2M>
 void launch_kc_fast_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
@@ -333,6 +335,7 @@ bool launch_kc_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
     case 2: launch_kc_fast_t<2>(pl, p, nb, s); break;
     case 3: launch_kc_fast_t<3>(pl, p, nb, s); break;
     case 4: launch_kc_fast_t<4>(pl, p, nb, s); break;
+    case 5: launch_kc_fast_t<5>(pl, p, nb, s); break;
     default: return false;
   }
   return true;
@@ -368,6 +371,7 @@ bool launch_k1_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
     case 2: launch_k1_fast_t<2>(pl, p, nb, s); break;
     case 3: launch_k1_fast_t<3>(pl, p, nb, s); break;
     case 4: launch_k1_fast_t<4>(pl, p, nb, s); break;
+    case 5: launch_k1_fast_t<5>(pl, p, nb, s); break;
     default: return false;
   }
   return true;
@@ -389,6 +393,7 @@ bool launch_k2_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
     case 2: launch_k2_fast_t<2>(pl, p, nb, s); break;
     case 3: launch_k2_fast_t<3>(pl, p, nb, s); break;
     case 4: launch_k2_fast_t<4>(pl, p, nb, s); break;
+    case 5: hipLaunchKernelGGL((fast::frbch_k2_fast<5, 1024>), dim3(pl.r / std::max(2, pl.tscr), nb), dim3(1024), pl.k2_fast_lds, s, p); break;
     default: return false;
   }
   return true;
@@ -458,7 +463,8 @@ int setup_fast(frbch_handle* h) {
       case 1: rc = allow_lds(h, fast::frbch_k1_fast<1>, pl.k1_fast_lds); break;
       case 2: rc = allow_lds(h, fast::frbch_k1_fast<2>, pl.k1_fast_lds); break;
       case 3: rc = allow_lds(h, fast::frbch_k1_fast<3>, pl.k1_fast_lds); break;
-      default: rc = allow_lds(h, fast::frbch_k1_fast<4>, pl.k1_fast_lds); break;
+      case 4: rc = allow_lds(h, fast::frbch_k1_fast<4>, pl.k1_fast_lds); break;
+      default: rc = allow_lds(h, fast::frbch_k1_fast<5>, pl.k1_fast_lds); break;
     }
     if (rc) return rc;
   }
@@ -470,7 +476,8 @@ int setup_fast(frbch_handle* h) {
       case 1: rc = allow_lds(h, fast::frbch_kc_fast<1>, kc_lds); break;
       case 2: rc = allow_lds(h, fast::frbch_kc_fast<2>, kc_lds); break;
       case 3: rc = allow_lds(h, fast::frbch_kc_fast<3>, kc_lds); break;
-      default: rc = allow_lds(h, fast::frbch_kc_fast<4>, kc_lds); break;
+      case 4: rc = allow_lds(h, fast::frbch_kc_fast<4>, kc_lds); break;
+      default: rc = allow_lds(h, fast::frbch_kc_fast<5>, kc_lds); break;
     }
     if (rc) return rc;
     const bool big = pl.fast_k2_nt == 1024;
@@ -504,7 +511,8 @@ int setup_fast(frbch_handle* h) {
       case 1: rc = big ? allow_lds(h, fast::frbch_k2_fast<1, 1024>, pl.k2_fast_lds) : allow_lds(h, fast::frbch_k2_fast<1, 512>, pl.k2_fast_lds); break;
       case 2: rc = big ? allow_lds(h, fast::frbch_k2_fast<2, 1024>, pl.k2_fast_lds) : allow_lds(h, fast::frbch_k2_fast<2, 512>, pl.k2_fast_lds); break;
       case 3: rc = big ? allow_lds(h, fast::frbch_k2_fast<3, 1024>, pl.k2_fast_lds) : allow_lds(h, fast::frbch_k2_fast<3, 512>, pl.k2_fast_lds); break;
-      default: rc = big ? allow_lds(h, fast::frbch_k2_fast<4, 1024>, pl.k2_fast_lds) : allow_lds(h, fast::frbch_k2_fast<4, 512>, pl.k2_fast_lds); break;
+      case 4: rc = big ? allow_lds(h, fast::frbch_k2_fast<4, 1024>, pl.k2_fast_lds) : allow_lds(h, fast::frbch_k2_fast<4, 512>, pl.k2_fast_lds); break;
+      default: rc = allow_lds(h, fast::frbch_k2_fast<5, 1024>, pl.k2_fast_lds); break;
     }
     if (rc) return rc;
   }

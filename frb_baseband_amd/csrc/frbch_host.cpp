@@ -199,7 +199,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
   pl->fast_k2_nt = (cfg.flags & 4u) ? 1024 : 512;
   pl->k1_fast_lds = pl->k2_fast_lds = 0;
   const bool want_wave = !(cfg.flags & 8u);
-  if (!(cfg.flags & 1u) && r >= 512 && r <= 4096 && in_bits == 2 && !pl->coherent) {   // the fast gather is written for 2-bit input
+  if (!(cfg.flags & 1u) && r >= 512 && r <= 8192 && in_bits == 2 && !pl->coherent) {   // the fast gather is written for 2-bit input
     const int m = (int)r / 256;
     const bool wave = want_wave && m <= 16;
     const int tps = 16 * m;
@@ -228,7 +228,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
       pl->k1_fast_lds = lds;
     }
   }
-  if (!(cfg.flags & 2u) && pl->c2 >= 512 && pl->c2 <= 4096 && pl->g >= 2 && !pl->coherent) {
+  if (!(cfg.flags & 2u) && pl->c2 >= 512 && pl->c2 <= 8192 && pl->g >= 2 && !pl->coherent) {
     const int m = pl->c2 / 256;
     const bool wave = want_wave && m <= 16 && !(cfg.flags & 4u);
     const int tps = 16 * m;
@@ -246,10 +246,13 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
     else if (wave && pl->tscr > 4 * spw)
       nw = 8;
     pl->fast_k2_nw = nw;
+    if (m == 32) pl->fast_k2_nt = 1024;           // 2C = 8192: one workgroup = 2 time samples (147 KB of LDS)
     const int tt = wave ? nw * spw : pl->fast_k2_nt / tps;
-    const size_t seq = (size_t)pl->c2 + pl->c2 / 8 + 8;
-    const size_t lds = (size_t)tt * seq * 8;
-    if (tt >= 1 && pl->tscr <= tt && tt <= (int)r && (size_t)tt * pl->ncol * 4 <= lds && lds <= lds_limit &&
+    // 2C = 8192: a workgroup may walk tscrunch/tt tiles and add them up in registers
+    const bool walk = m == 32 && pl->nif == 1 && pl->tscr > tt && pl->tscr % tt == 0 && pl->tscr <= (int)r;
+    const size_t seq = (size_t)pl->c2 + pl->c2 / 8 + (m == 32 ? 0 : 8);
+    const size_t lds = (size_t)tt * seq * 8 + (walk ? (size_t)pl->c * 4 : 0);   // + the row of sub-tile sums
+    if (tt >= 1 && (pl->tscr <= tt || walk) && tt <= (int)r && (size_t)tt * pl->ncol * 4 <= lds && lds <= lds_limit &&
         (tt * pl->g) % 2 == 0) {
       pl->fast_k2_log2m = ilog2(m);
       pl->fast_k2_wave = wave ? 1 : 0;

@@ -54,7 +54,11 @@ CASES = [
     (-32.0, 1024, 0.3, dict(dm=56.7, coherent=1, freq=400.0, tscr=4)),
     (-32.0, 512, 0.15, dict(dm=26.7, coherent=1, freq=350.0, pol=4, tscr=2, nbit=16)),
     (32.0, 2048, 0.6, dict(dm=56.7, coherent=1, freq=1400.0, freq_res=4096)),   # BASELINE config 5 shape: -F2048:4096 -D 56.7 -F2048:D
-    (64.0, 4096, 1.1, dict(tscr=8)),                         # BASELINE config 4 shape (-t 8 -F4096:8192): generic kernels, 2 blocks
+    (64.0, 4096, 1.1, dict(tscr=8)),                         # BASELINE config 4 shape (-t 8 -F4096:8192), 2 blocks: M = 32 barrier kernels, K2 walks 4 sub-tiles
+    (64.0, 4096, 1.1, dict(tscr=8, flags=3)),                # the same through the generic kernels
+    (-64.0, 4096, 1.1, {}),                                  # M = 32, -t 1, LSB
+    (64.0, 4096, 1.1, dict(pol=4, tscr=2, nbit=16)),         # M = 32, coherency products
+    (64.0, 4096, 1.1, dict(pol=4, tscr=4)),                  # four products and tscrunch > 2: generic K2 behind the M = 32 K1
 ]
 
 
