@@ -217,6 +217,8 @@ template <int LOG2M>
 void launch_k1_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
   // persistent over blocks: the resident workgroups each keep their branch group and loop over the batch
   p.nblk = nb;
+  static const int stag_env = getenv("FRBCH_K1_STAG") ? atoi(getenv("FRBCH_K1_STAG")) : 0;   // experiments
+  p.stag = stag_env;
   const int kg = pl.fast_k1_g;            // branches per workgroup (<= pl.g, the layout group)
   {
     static const int ks[6] = {1, 2, 3, 4, 8, 12};
@@ -228,6 +230,14 @@ void launch_k1_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
     }
   }
   const uint32_t ngrp = (uint32_t)(pl.c2 / kg);
+  static const char* stamp_path = getenv("FRBCH_STAMPS");   // diagnostic: phase stamps of one block, dumped after every launch
+  static unsigned long long* stamp_buf = nullptr;
+  const size_t stamp_n = (size_t)ngrp * 16 * 16;
+  if (stamp_path) {
+    if (!stamp_buf) (void)hipMalloc((void**)&stamp_buf, (size_t)4096 * 16 * 16 * 8);
+    (void)hipMemsetAsync(stamp_buf, 0, stamp_n * 8, s);
+    p.stamps = stamp_buf;
+  }
   static const uint32_t cap_env = getenv("FRBCH_K1_MAXWG") ? (uint32_t)atoi(getenv("FRBCH_K1_MAXWG")) : 0u;   // experiments
   const uint32_t resident = cap_env ? cap_env : 256u * (uint32_t)std::max<size_t>(1, (160 * 1024) / pl.k1_fast_lds);
   uint32_t ny = std::max<uint32_t>(1, std::min<uint32_t>(nb, resident / std::max<uint32_t>(1, ngrp)));
@@ -242,6 +252,12 @@ void launch_k1_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
       hipLaunchKernelGGL((fast::frbch_k1_wave<3, 16, 2>), dim3(ngrp, ny), dim3(1024), pl.k1_fast_lds, s, p);
     else
       hipLaunchKernelGGL((fast::frbch_k1_wave<LOG2M, 8, 1>), dim3(ngrp, ny), dim3(512), pl.k1_fast_lds, s, p);
+  }
+  if (stamp_path && nb > 8 * ny) {
+    std::vector<unsigned long long> hst(stamp_n);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(hst.data(), stamp_buf, stamp_n * 8, hipMemcpyDeviceToHost);
+    if (FILE* f = fopen(stamp_path, "wb")) { fwrite(hst.data(), 8, stamp_n, f); fclose(f); }
   }
 }
 constexpr uint32_t kFusedStatWgs = 2048;   // persistent K2 workgroups (= rows of partial sums per thread row) while statistics are fused

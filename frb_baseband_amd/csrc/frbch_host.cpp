@@ -216,15 +216,16 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
     } else if (wave && m == 16) {
       kind = 4;                                   // R = 4096: 8 waves, two per sequence, 4 branches
     }
-    const size_t lds = (size_t)kg * seq * 8 + (size_t)r * (kg / 2) + 128;
+    const size_t lds = (size_t)kg * seq * 8 + (size_t)r * (kg / 2) + 128 + (wave ? (size_t)kg * 132 : 0);   // + unpack LUT + coarse delay factors + arrival counters
     const size_t generic_lds = (size_t)gfast * seq1;   // fallback for unaligned calls keeps the layout
+    static const int gl_env = getenv("FRBCH_GL") ? atoi(getenv("FRBCH_GL")) : 0;   // experiments: layout group = workgroup group
     if (gfast <= pl->c2 && lds <= lds_limit && generic_lds <= lds_limit) {
       pl->fast_k1_log2m = ilog2(m);
       pl->fast_k1_wave = wave ? 1 : 0;
       pl->fast_k1_kind = kind;
       pl->fast_k1_g = kg;
-      pl->g = gfast;
-      pl->k1_lds = generic_lds;
+      pl->g = (gl_env && gl_env == kg) ? kg : gfast;
+      pl->k1_lds = (size_t)pl->g * seq1;
       pl->k1_fast_lds = lds;
     }
   }

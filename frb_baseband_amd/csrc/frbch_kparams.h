@@ -65,7 +65,7 @@ struct KParams {
   int coherent;             // 1 = that pipeline
   int nfilt_pos;            // channel samples discarded at the start of every block (overlap-save)
   int keep;                 // channel samples kept per block, a multiple of tscr
-  int reserved_i;
+  int stag;                 // K1 wave kernels: the second half of a workgroup's waves starts every block stag*64 cycles late (0 = off)
   uint64_t hop;             // real samples between block starts: N, or 2C*keep with overlap-save
   cf* spill2;               // [nblk][2C][R]  chirped spectrum P'[k'][j], j axis in bit-reversed position
   const cf* chirp;          // [2C][R]        Hermitian-extended dedispersion kernel, same order
@@ -74,6 +74,7 @@ struct KParams {
   uint64_t stat_limit;      // ... of the rows below this absolute row of power_out (the end of the rescale interval)
   uint32_t nblk;            // blocks in this launch (persistent kernels loop over them)
   uint32_t dbg;             // timing-only ablations (cfg.flags >> 8); results are wrong when set
+  unsigned long long* stamps; // diagnostic builds of the wave K1: s_memtime stamps [workgroup][wave][16] of one block; null = off
 };
 
 struct StatParams {

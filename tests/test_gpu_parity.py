@@ -24,6 +24,9 @@ CASES = [
     (32.0, 1024, 0.14, dict(flags=32)),                      # one wave per sequence in K2
     (-32.0, 1024, 0.14, dict(flags=32, pol=4, tscr=4)),
     (32.0, 1024, 0.14, dict(flags=16, pol=4)),               # 4 sequences per K2 workgroup
+    (32.0, 1024, 0.14, dict(flags=64)),                      # K1 variants: 8 waves x 4 branches, two waves per sequence
+    (32.0, 1024, 0.14, dict(flags=128)),                     # 16 waves x 8 branches, two waves per sequence
+    (-32.0, 1024, 0.14, dict(flags=192, pol=4)),             # 4 waves x 4 branches
     (32.0, 1024, 0.14, dict(flags=8)),                       # barrier variants of the fast kernels
     (-32.0, 1024, 0.14, dict(flags=8, pol=4, tscr=4)),
     (16.0, 256, 0.04, dict(flags=8, pol=4, tscr=8)),
