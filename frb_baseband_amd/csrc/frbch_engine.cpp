@@ -217,7 +217,7 @@ template <int LOG2M>
 void launch_k1_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
   // persistent over blocks: the resident workgroups each keep their branch group and loop over the batch
   p.nblk = nb;
-  static const int stag_env = getenv("FRBCH_K1_STAG") ? atoi(getenv("FRBCH_K1_STAG")) : 0;   // experiments
+  static const int stag_env = getenv("FRBCH_K1_STAG") ? atoi(getenv("FRBCH_K1_STAG")) : 3;   // priority schedule (3: the halves swap priority behind the forward passes; measured 1.96 -> 1.94 ms)
   p.stag = stag_env;
   const int kg = pl.fast_k1_g;            // branches per workgroup (<= pl.g, the layout group)
   {

@@ -65,7 +65,7 @@ struct KParams {
   int coherent;             // 1 = that pipeline
   int nfilt_pos;            // channel samples discarded at the start of every block (overlap-save)
   int keep;                 // channel samples kept per block, a multiple of tscr
-  int stag;                 // K1 wave kernels: the second half of a workgroup's waves starts every block stag*64 cycles late (0 = off)
+  int stag;                 // K1 wave kernels: priority schedule of the two halves of a workgroup (bit mask, see the kernel)
   uint64_t hop;             // real samples between block starts: N, or 2C*keep with overlap-save
   cf* spill2;               // [nblk][2C][R]  chirped spectrum P'[k'][j], j axis in bit-reversed position
   const cf* chirp;          // [2C][R]        Hermitian-extended dedispersion kernel, same order
