@@ -73,6 +73,7 @@ SYMBOLS = {
     "frbch_get_info": (C.c_int, [_P, C.POINTER(FrbchInfo)]),
     "frbch_reset": (C.c_int, [_P]),
     "frbch_run_file": (C.c_int, [_P, C.c_char_p, C.c_char_p]),
+    "frbch_run_scan": (C.c_int, [C.POINTER(_P), C.c_uint32, C.POINTER(C.c_char_p), C.c_char_p]),
     "frbch_push": (C.c_int, [_P, _P, C.c_size_t]),
     "frbch_flush": (C.c_int, [_P]),
     "frbch_pull": (C.c_long, [_P, _P, C.c_size_t]),

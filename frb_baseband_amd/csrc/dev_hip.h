@@ -58,6 +58,9 @@ static inline int dev_d2h(void* h, const void* d, size_t n, dev_stream_t s) {
 static inline int dev_d2d(void* d, const void* s_, size_t n, dev_stream_t s) {
   return hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s) == hipSuccess ? 0 : -1;
 }
+static inline int dev_copy2d(void* d, size_t dpitch, const void* s_, size_t spitch, size_t width, size_t height, dev_stream_t s) {
+  return hipMemcpy2DAsync(d, dpitch, s_, spitch, width, height, hipMemcpyDeviceToDevice, s) == hipSuccess ? 0 : -1;
+}
 static inline int dev_memset(void* d, int v, size_t n, dev_stream_t s) {
   return hipMemsetAsync(d, v, n, s) == hipSuccess ? 0 : -1;
 }

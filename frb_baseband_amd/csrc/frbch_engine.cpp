@@ -90,6 +90,10 @@ struct frbch_handle {
   size_t d_out_cap = 0;
   std::vector<uint8_t> outq;
   size_t outq_pos = 0;
+  // frbch_run_scan: rows go into this IF's columns of a pitched device buffer shared by the IFs of the scan
+  uint8_t* sink = nullptr;         // first byte of this IF's columns in line 0
+  size_t sink_line_pitch = 0;      // bytes per (row, product) line of the shared buffer
+  uint64_t sink_rows = 0, sink_rows_cap = 0;
 
   // profiling
   bool profiling = false;
@@ -1092,6 +1096,15 @@ int stream_begin(frbch_handle* h, const uint8_t* first_frame) {
 
 int queue_rows(frbch_handle* h, uint64_t rows) {
   if (!rows) return FRBCH_OK;
+  if (h->sink) {   // scan mode: frequency concatenation on the device, one 2-D copy per batch
+    if (h->sink_rows + rows > h->sink_rows_cap) return fail(h, FRBCH_E_CAPACITY, "scan row buffer too small");
+    const size_t seg = h->pl.row_bytes / h->pl.nif;            // bytes of one product line of this IF
+    CHECK_DEV(h, dev_copy2d(h->sink + h->sink_rows * h->pl.nif * h->sink_line_pitch, h->sink_line_pitch, h->d_out, seg, seg,
+                            rows * h->pl.nif, h->stream), "copy rows into the scan buffer");
+    CHECK_DEV(h, dev_sync(h->stream), "sync");
+    h->sink_rows += rows;
+    return FRBCH_OK;
+  }
   const size_t nbytes = rows * h->pl.row_bytes;
   if (h->outq_pos && h->outq_pos == h->outq.size()) {
     h->outq.clear();
@@ -1265,5 +1278,115 @@ extern "C" int frbch_run_file(frbch_handle* h, const char* vdif_path, const char
   if (!rc && !header_done) rc = fail(h, FRBCH_E_FORMAT, "input holds no complete VDIF frame");
   fclose(in);
   if (close(fd) != 0 && !rc) rc = fail(h, FRBCH_E_IO, std::string("close: ") + strerror(errno));
+  return rc;
+}
+
+// =============================================================================================
+// One scan, several IFs on one GPU: replaces N digifil processes + N FIFOs + splice
+// =============================================================================================
+extern "C" int frbch_run_scan(frbch_handle* const* ifs, uint32_t nif, const char* const* vdif_paths, const char* out_fil) {
+  if (!ifs || !nif || !vdif_paths || !out_fil || !ifs[0]) return FRBCH_E_ARG;
+  frbch_handle* h0 = ifs[0];
+  for (uint32_t i = 0; i < nif; ++i) {
+    if (!ifs[i] || !vdif_paths[i]) return fail(h0, FRBCH_E_ARG, "null handle or path in the scan");
+    const Plan &a = ifs[i]->pl, &b = h0->pl;
+    if (a.c != b.c || a.nif != b.nif || a.tscr != b.tscr || a.row_bytes != b.row_bytes || ifs[i]->cfg.nbit_out != h0->cfg.nbit_out ||
+        ifs[i]->device != h0->device || a.tsamp_s != b.tsamp_s)
+      return fail(h0, FRBCH_E_ARG, "the IFs of a scan must share device, nchan, tscrunch, nbit and products");
+    if (ifs[i]->have_vdif) return fail(h0, FRBCH_E_STATE, "frbch_run_scan needs freshly opened (or reset) handles");
+  }
+  CHECK_DEV(h0, dev_set(h0->device), "hipSetDevice");
+  const Plan& pl = h0->pl;
+  const size_t seg = pl.row_bytes / pl.nif, line_pitch = seg * nif, row_pitch = line_pitch * pl.nif;
+  const uint64_t rows_cap = 2 * (pl.interval_rows + 2ull * pl.maxb * pl.rows_per_block) + 16;
+  uint8_t* d_rows = nullptr;
+  CHECK_DEV(h0, dev_malloc((void**)&d_rows, rows_cap * row_pitch), "hipMalloc(scan rows)");
+  std::vector<FILE*> in(nif, nullptr);
+  int fd = -1, rc = FRBCH_OK;
+  uint8_t* stage = nullptr;            // pinned host staging of finished rows
+  const size_t stage_bytes = 64u << 20;
+  auto cleanup = [&]() {
+    for (FILE* f : in) if (f) fclose(f);
+    if (fd >= 0) close(fd);
+    dev_host_free(stage);
+    dev_free(d_rows);
+    for (uint32_t i = 0; i < nif; ++i) ifs[i]->sink = nullptr;
+  };
+  for (uint32_t i = 0; i < nif && !rc; ++i) {
+    in[i] = fopen(vdif_paths[i], "rb");
+    if (!in[i]) rc = fail(h0, FRBCH_E_IO, std::string("cannot open ") + vdif_paths[i] + ": " + strerror(errno));
+    ifs[i]->sink = d_rows + (size_t)i * seg;
+    ifs[i]->sink_line_pitch = line_pitch;
+    ifs[i]->sink_rows = 0;
+    ifs[i]->sink_rows_cap = rows_cap;
+  }
+  if (!rc) {
+    fd = open(out_fil, O_WRONLY | O_CREAT | O_TRUNC, 0644);   // no O_EXCL: may be a FIFO (INSTALL.md:32-35)
+    if (fd < 0) rc = fail(h0, FRBCH_E_IO, std::string("cannot open ") + out_fil + ": " + strerror(errno));
+  }
+  if (!rc && dev_host_alloc((void**)&stage, stage_bytes) != 0) rc = fail(h0, FRBCH_E_NOMEM, "pinned staging buffer");
+  bool header_done = false;
+  // write the rows every IF has delivered; rows only some IFs have stay in the buffer (moved to its top)
+  auto drain = [&](bool final_) -> int {
+    uint64_t n = UINT64_MAX, most = 0;
+    for (uint32_t i = 0; i < nif; ++i) {
+      if (!ifs[i]->have_vdif) return FRBCH_OK;      // nothing can be written before every IF has started
+      n = std::min(n, ifs[i]->sink_rows);
+      most = std::max(most, ifs[i]->sink_rows);
+    }
+    if (!header_done) {
+      for (uint32_t i = 1; i < nif; ++i)
+        if (fabs(ifs[i]->tstart_mjd - h0->tstart_mjd) > 0.5 * pl.tsamp_s / 86400.0)
+          return fail(h0, FRBCH_E_FORMAT, "the IFs of the scan do not start at the same time");
+      const std::vector<uint8_t> hdr = sigproc_header(h0->cfg, pl, h0->tstart_mjd, (int)(pl.c * nif));
+      if (!write_all(fd, hdr.data(), hdr.size())) return fail(h0, FRBCH_E_IO, std::string("write: ") + strerror(errno));
+      header_done = true;
+    }
+    for (uint64_t r0 = 0; r0 < n;) {
+      const uint64_t nr = std::min<uint64_t>(n - r0, stage_bytes / row_pitch);
+      if (!nr) return fail(h0, FRBCH_E_CAPACITY, "row larger than the staging buffer");
+      CHECK_DEV(h0, dev_d2h(stage, d_rows + r0 * row_pitch, nr * row_pitch, h0->stream), "download scan rows");
+      CHECK_DEV(h0, dev_sync(h0->stream), "sync");
+      if (!write_all(fd, stage, nr * row_pitch)) return fail(h0, FRBCH_E_IO, std::string("write: ") + strerror(errno));
+      r0 += nr;
+    }
+    if (final_) return FRBCH_OK;                      // cut to the shortest IF, as splice does
+    for (uint32_t i = 0; i < nif; ++i) {
+      frbch_handle* h = ifs[i];
+      const uint64_t left = h->sink_rows - n;
+      if (left && n) {                                // via this IF's own staging area: the two regions may overlap
+        if (left * h->pl.row_bytes > h->d_out_cap) return fail(h0, FRBCH_E_CAPACITY, "scan backlog exceeds the staging area");
+        CHECK_DEV(h0, dev_copy2d(h->d_out, seg, h->sink + n * pl.nif * line_pitch, line_pitch, seg, left * pl.nif, h->stream), "move backlog");
+        CHECK_DEV(h0, dev_copy2d(h->sink, line_pitch, h->d_out, seg, seg, left * pl.nif, h->stream), "move backlog");
+        CHECK_DEV(h0, dev_sync(h->stream), "sync");
+      }
+      h->sink_rows = left;
+    }
+    (void)most;
+    return FRBCH_OK;
+  };
+  std::vector<uint8_t> buf(32u << 20);
+  std::vector<bool> eof(nif, false);
+  while (!rc) {
+    bool any = false;
+    for (uint32_t i = 0; i < nif && !rc; ++i) {
+      frbch_handle* h = ifs[i];
+      if (eof[i] || (h->have_vdif && h->blocks_budget == 0)) continue;
+      const size_t n = fread(buf.data(), 1, buf.size(), in[i]);
+      if (!n) { eof[i] = true; continue; }
+      any = true;
+      if ((rc = frbch_push(h, buf.data(), n)) && h != h0) fail(h0, rc, std::string("IF ") + std::to_string(i) + ": " + h->err);
+    }
+    if (!rc) rc = drain(false);
+    if (!any) break;
+  }
+  for (uint32_t i = 0; i < nif && !rc; ++i)
+    if ((rc = frbch_flush(ifs[i])) && ifs[i] != h0) fail(h0, rc, std::string("IF ") + std::to_string(i) + ": " + ifs[i]->err);
+  if (!rc) rc = drain(true);
+  if (!rc && !header_done) rc = fail(h0, FRBCH_E_FORMAT, "an input holds no complete VDIF frame");
+  const int fd_ = fd;
+  fd = -1;
+  if (fd_ >= 0 && close(fd_) != 0 && !rc) rc = fail(h0, FRBCH_E_IO, std::string("close: ") + strerror(errno));
+  cleanup();
   return rc;
 }

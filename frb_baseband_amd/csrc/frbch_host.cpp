@@ -337,7 +337,7 @@ int sigproc_telescope_id(const char* name) {
   return 0;
 }
 
-std::vector<uint8_t> sigproc_header(const frbch_config& cfg, const Plan& pl, double tstart_mjd) {
+std::vector<uint8_t> sigproc_header(const frbch_config& cfg, const Plan& pl, double tstart_mjd, int nchans_total) {
   std::vector<uint8_t> v;
   put_str(v, "HEADER_START");
   put_i(v, "telescope_id", sigproc_telescope_id(cfg.telescope));
@@ -362,7 +362,7 @@ std::vector<uint8_t> sigproc_header(const frbch_config& cfg, const Plan& pl, dou
   put_i(v, "nbits", cfg.nbit_out == -32 ? 32 : cfg.nbit_out);
   put_d(v, "fch1", pl.fch1);
   put_d(v, "foff", pl.foff);
-  put_i(v, "nchans", pl.c);
+  put_i(v, "nchans", nchans_total > 0 ? nchans_total : pl.c);   // > 0: several IFs side by side (frbch_run_scan)
   put_i(v, "nifs", pl.nif);
   put_d(v, "refdm", cfg.dm);
   put_str(v, "HEADER_END");

@@ -65,7 +65,7 @@ std::string coherent_geometry(double freq_mhz, double bw_mhz, uint32_t nchan, ui
 constexpr double kDmDispersion = 2.41e-4;   // DSPSR's constant: delay = DM / (2.41e-4 nu_MHz^2) s
 constexpr uint32_t kMaxCoherentFreqRes = 8192;
 
-std::vector<uint8_t> sigproc_header(const frbch_config& cfg, const Plan& plan, double tstart_mjd);
+std::vector<uint8_t> sigproc_header(const frbch_config& cfg, const Plan& plan, double tstart_mjd, int nchans_total = 0);
 double sigproc_angle(const char* text);
 int sigproc_telescope_id(const char* name);
 

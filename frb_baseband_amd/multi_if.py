@@ -102,21 +102,72 @@ def ifall_name(experiment: str, st: str, scanname: str, pol: int) -> str:
     return f"{experiment}_{st}_no0{scanname}_IFall_vdif_pol{pol}.fil"
 
 
+def run_scan(channelisers, vdif_paths, out_fil: str) -> None:
+    """One GPU, several IFs, one output: ``frbch_run_scan`` (include/frbch.h).  ``channelisers`` are freshly opened
+    ``Channeliser`` objects in splice order (highest IF first, base2fil.sh:350,367); the frequency concatenation
+    happens in device memory and a single IFall filterbank is written (no per-IF files, FIFOs or splice)."""
+    import ctypes as C
+    from . import channeliser as ch
+    n = len(channelisers)
+    assert n == len(vdif_paths) and n > 0
+    lib = channelisers[0].lib
+    handles = (C.c_void_p * n)(*[c._h for c in channelisers])
+    paths = (C.c_char_p * n)(*[os.fsencode(p) for p in vdif_paths])
+    rc = lib.frbch_run_scan(handles, n, paths, os.fsencode(out_fil))
+    if rc < 0:
+        raise (ch.InputError if rc == -1 else ch.RunError)(channelisers[0]._err(rc))
+
+
 def process_scan(vdif_by_if: dict, *, freq_lsb_0: float, bw: float, nchan: int, nsec: float, start: float = 0.0,
                  pol: int = 2, nbit: int = 8, tscrunch: int = 1, keepBP: bool = False, source: str = "unknown",
                  ra: str = "00:00:00.0", dec: str = "00:00:00.0", telescope: str = "ONSALA85",
                  out_dir: str, out_name: str = "IFall.fil", rank: int = 0, world: int = 1, local_device: int = 0,
-                 barrier=None, lib=None):
+                 barrier=None, lib=None, direct: bool = False):
     """Channelise this rank's IFs (one handle per IF on GPU ``local_device``) into
     ``out_dir/<vdif basename>_pol<pol>.fil`` and, on rank 0 after ``barrier()``, splice all IFs.
 
     ``vdif_by_if``: {IF number: path}.  No data-path collective: ranks only meet at the barrier.
+    ``direct=True``: the rank's IFs are concatenated on its GPU (``run_scan``) into one ``<out_name>.rank<r>`` piece
+    and rank 0 splices the world's pieces (with one rank: the IFall file is written directly, no per-IF files).
     Returns the spliced path on rank 0, else None."""
     from . import channeliser as ch
     from . import process_vdif as pv
     nif = len(vdif_by_if)
     plans = {p.index: p for p in plan_ifs(nif, freq_lsb_0, bw)}
     mine = shard(nif, world, rank)
+    if direct:
+        from . import digifil_args
+        # ranks own contiguous runs of the splice order so that their pieces concatenate without interleaving
+        order = splice_order(nif)
+        per = (nif + world - 1) // world
+        mine = order[rank * per:(rank + 1) * per]
+        chans, paths = [], []
+        for i in mine:
+            p = plans[i]
+            hdr = pv.make_hdr(source, p.freq_mhz, vdif_by_if[i], pol=pol, usb=(p.sideband == "u"), ra=ra, dec=dec, bw=bw,
+                              telescope=telescope)
+            cmd = pv.digifil_command(hdr, os.path.join(out_dir, "unused.fil"), start, nsec, nchan, pol, nbit, tscrunch, 1,
+                                     0.0, False, keepBP)
+            cfg, _h, _o = digifil_args.parse(cmd, lib=lib)
+            cfg.device = local_device
+            chans.append(ch.Channeliser(cfg, lib))
+            paths.append(vdif_by_if[i])
+        out_path = os.path.join(out_dir, out_name)
+        piece = out_path if world == 1 else f"{out_path}.rank{rank}"
+        try:
+            if chans:
+                run_scan(chans, paths, piece)
+        finally:
+            for c in chans:
+                c.close()
+        if barrier is not None:
+            barrier()
+        if rank != 0:
+            return None
+        if world > 1:
+            pieces = [f"{out_path}.rank{r}" for r in range(world) if order[r * per:(r + 1) * per]]
+            splice(pieces, out_path)
+        return out_path
     for i in mine:
         p = plans[i]
         path = vdif_by_if[i]

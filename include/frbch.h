@@ -139,6 +139,17 @@ int frbch_reset(frbch_handle* h);
  * O_WRONLY|O_CREAT|O_TRUNC without O_EXCL (INSTALL.md:32-35), never unlinked, never seeked. */
 int frbch_run_file(frbch_handle* h, const char* vdif_path, const char* out_fil);
 
+/* ---- one scan, several IFs on one GPU -------------------------------------
+ * What base2fil.sh does with N digifil processes, N FIFOs and sigproc `splice`
+ * (base2fil.sh:348-350,404-448), in one call: `ifs` are freshly opened handles on the same device with the same
+ * nchan / tscrunch / nbit / products, listed like base2fil's splice_list: highest IF first (:350,367);
+ * vdif_paths[i] is the per-IF VDIF of ifs[i].  Every IF's rows are copied into its columns of one pitched device
+ * buffer (the frequency concatenation happens in HBM), and ONE SIGPROC file is written -- the
+ * <exp>_<st>_no0<scan>_IFall_vdif_pol<pol>.fil of base2fil.sh:389: nchans = nif*nchan, fch1 of ifs[0], rows cut
+ * to the shortest IF as splice does.  out_fil may be a FIFO (same open flags as frbch_run_file).
+ * Errors are reported through frbch_last_error(ifs[0]). */
+int frbch_run_scan(frbch_handle* const* ifs, uint32_t nif, const char* const* vdif_paths, const char* out_fil);
+
 /* ---- streaming host path ----------------------------------------------------------------- */
 /* push whole or partial frames (byte stream starting at a frame boundary on the first call) */
 int frbch_push(frbch_handle* h, const uint8_t* frames, size_t nbytes);

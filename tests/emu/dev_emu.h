@@ -53,6 +53,10 @@ static inline void dev_free(void* p) { free(p); }
 static inline int dev_h2d(void* d, const void* h, size_t n, dev_stream_t) { memcpy(d, h, n); return 0; }
 static inline int dev_d2h(void* h, const void* d, size_t n, dev_stream_t) { memcpy(h, d, n); return 0; }
 static inline int dev_d2d(void* d, const void* s, size_t n, dev_stream_t) { memmove(d, s, n); return 0; }
+static inline int dev_copy2d(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, dev_stream_t) {
+  for (size_t r = 0; r < height; ++r) memmove((char*)d + r * dpitch, (const char*)s + r * spitch, width);
+  return 0;
+}
 static inline int dev_memset(void* d, int v, size_t n, dev_stream_t) { memset(d, v, n); return 0; }
 static inline int dev_sync(dev_stream_t) { return 0; }
 static inline int dev_stream_create(dev_stream_t* s) { *s = (void*)1; return 0; }

@@ -186,3 +186,33 @@ def test_multi_if_scan_on_device(tmp_path):
     assert np.abs(got.data.astype(int) - want.astype(int)).max() <= 1
     assert np.count_nonzero(got.data != want) <= 2e-4 * want.size
     assert got.header["nchans"] == 2048 and got.header["fch1"] == pytest.approx(parts[0].header["fch1"])
+
+
+def test_direct_scan_on_device_equals_spliced_per_if_runs(tmp_path):
+    """frbch_run_scan (config-3 shape: several 32 MHz IFs, -d4, on ONE GPU): the IFall file written
+    from the pitched device buffer is byte-identical to splice() of the per-IF files of the same library, and within
+    the stated tolerance of the oracle."""
+    d1, d2 = str(tmp_path / "direct"), str(tmp_path / "perif")
+    os.makedirs(d1)
+    os.makedirs(d2)
+    raws, vd = {}, {}
+    for i in (1, 2, 3, 4):
+        raws[i] = synth.make_vdif(0.27, bw_mhz=32.0, nchan=1024, if_index=i)
+        vd[i] = os.path.join(d1, f"x_ef_no0001_IF{i}.vdif")
+        raws[i].tofile(vd[i])
+    kw = dict(freq_lsb_0=1340.0, bw=32.0, nchan=1024, nsec=0.27, pol=4, tscrunch=2, source="R3", ra="01:58:00.75",
+              dec="65:43:00.3")
+    with contextlib.redirect_stdout(io.StringIO()):
+        out = multi_if.process_scan(vd, out_dir=d1, direct=True, **kw)
+        ref = multi_if.process_scan(vd, out_dir=d2, **kw)
+    a, b = open(out, "rb").read(), open(ref, "rb").read()
+    ga, gb = sigproc.read_fil(a), sigproc.read_fil(b)
+    assert ga.header == gb.header
+    assert ga.data.shape == gb.data.shape == (ga.data.shape[0], 4, 4096)
+    assert np.array_equal(ga.data, gb.data)
+    plan = multi_if.plan_ifs(4, 1340.0, 32.0)[3]           # highest IF: first 1024 columns
+    cfg = o.Config(bw_mhz=32.0, freq_mhz=plan.freq_mhz, nchan=1024, total_s=0.27, pol_mode=4, tscrunch=2, source="R3",
+                   ra="01:58:00.75", dec="65:43:00.3")
+    want = sigproc.read_fil(o.channelise(raws[4], cfg)).data
+    assert np.abs(ga.data[:, :, :1024].astype(int) - want.astype(int)).max() <= 1
+    assert np.count_nonzero(ga.data[:, :, :1024] != want) <= 2e-4 * want.size

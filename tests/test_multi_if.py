@@ -70,3 +70,58 @@ def test_two_rank_scan_equals_oracle_splice(emu_lib, tmp_path):
     fch = [p.header["fch1"] for p in parts]
     assert fch == sorted(fch, reverse=True)                 # descending frequency across IFs
     assert fch[0] - fch[1] == pytest.approx(16.0)
+
+
+def _oracle_ifall(raws, nif, bw, nchan, secs, **kw):
+    parts = []
+    for i in range(nif, 0, -1):
+        plan = multi_if.plan_ifs(nif, 1340.0, bw)[i - 1]
+        cfg = o.Config(bw_mhz=bw if plan.sideband == "u" else -bw, freq_mhz=plan.freq_mhz, nchan=nchan, total_s=secs,
+                       source="unknown", **kw)
+        parts.append(sigproc.read_fil(o.channelise(raws[i], cfg)))
+    return parts, np.concatenate([p.data for p in parts], axis=2)
+
+
+def _direct_scan(lib, tmp_path, nif, bw, nchan, secs, pol=2, tscrunch=1, nbit=8, lengths=None):
+    d = str(tmp_path)
+    raws, vd = {}, {}
+    for i in range(1, nif + 1):
+        raws[i] = synth.make_vdif((lengths or {}).get(i, secs), bw_mhz=bw, nchan=nchan, if_index=i)
+        vd[i] = os.path.join(d, f"x_ef_no0001_IF{i}.vdif")
+        raws[i].tofile(vd[i])
+    out = multi_if.process_scan(vd, freq_lsb_0=1340.0, bw=bw, nchan=nchan, nsec=secs, out_dir=d, lib=lib, direct=True,
+                                pol=pol, tscrunch=tscrunch, nbit=nbit, ra="01:00:00.0", dec="02:00:00.0")
+    assert sorted(f for f in os.listdir(d) if f.endswith(".fil")) == ["IFall.fil"]      # no per-IF products
+    return raws, sigproc.read_fil(out)
+
+
+def test_direct_scan_on_one_device_equals_oracle_splice(emu_lib, tmp_path):
+    """frbch_run_scan (8f row 1): 4 IFs concatenated in device memory == splice of the per-IF oracle outputs."""
+    raws, got = _direct_scan(emu_lib, tmp_path, 4, 16.0, 32, 0.02)
+    parts, want = _oracle_ifall(raws, 4, 16.0, 32, 0.02)
+    assert got.data.shape == want.shape == (parts[0].data.shape[0], 1, 128)
+    assert np.abs(got.data.astype(int) - want.astype(int)).max() <= 1
+    assert np.count_nonzero(got.data != want) <= 2e-5 * want.size
+    assert got.header["nchans"] == 128 and got.header["nifs"] == 1
+    assert got.header["fch1"] == pytest.approx(parts[0].header["fch1"])
+    assert got.header["tstart"] == pytest.approx(parts[0].header["tstart"], abs=1e-12)
+
+
+def test_direct_scan_four_products_and_unequal_inputs(emu_lib, tmp_path):
+    """-d4 -t2 16-bit rows ([t][product][IF chans]); the second IF is one block longer: rows cut to the shortest."""
+    raws, got = _direct_scan(emu_lib, tmp_path, 3, 16.0, 32, 0.02, pol=4, tscrunch=2, nbit=16, lengths={2: 0.03})
+    parts, want = _oracle_ifall(raws, 3, 16.0, 32, 0.02, pol_mode=4, tscrunch=2, nbit=16)
+    assert got.data.shape == want.shape == (parts[0].data.shape[0], 4, 96)
+    assert np.abs(got.data.astype(int) - want.astype(int)).max() <= 1
+    # 16-bit codes: +-1 at rounding ties within the stated tolerance (parity_util: 1e-5 of the samples per code unit of sigma)
+    assert np.count_nonzero(got.data != want) <= 1.0e-5 * (32767.5 / 6.0) * want.size
+
+
+def test_direct_scan_rejects_mixed_geometry(emu_lib, tmp_path):
+    from frb_baseband_amd import channeliser as ch
+    a = ch.Channeliser(ch.new_config(emu_lib, bw_mhz=16.0, nchan=32, total_s=0.02), emu_lib)
+    b = ch.Channeliser(ch.new_config(emu_lib, bw_mhz=16.0, nchan=64, total_s=0.02), emu_lib)
+    with pytest.raises(ch.InputError, match="share"):
+        multi_if.run_scan([a, b], ["/nonexistent/a.vdif", "/nonexistent/b.vdif"], str(tmp_path / "o.fil"))
+    a.close()
+    b.close()
