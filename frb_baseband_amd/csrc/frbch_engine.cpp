@@ -58,6 +58,7 @@ struct frbch_handle {
   cf *spill = nullptr, *s_dc = nullptr, *p0 = nullptr;
   // coherent dedispersion (-F C:D): second spill, kernel table, channel-major power
   cf *spill2 = nullptr, *chirp = nullptr;
+  int coh_order_m = 0;         // order of the fine bins in spill2 / chirp: 0 bit-reversed (generic K1/K3), M: register passes
   float* ptmp = nullptr;
   // rescale state
   float *offset = nullptr, *scale = nullptr;
@@ -418,6 +419,36 @@ bool launch_k2_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   }
   return true;
 }
+bool launch_k2c_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
+  const Plan& pl = h->pl;
+  if (!pl.coh_fast_c) return false;
+  const int tt = 1024 / (16 << pl.coh_fast_c);
+  const dim3 grid(pl.r / tt, nb);
+  switch (pl.coh_fast_c) {
+    case 1: hipLaunchKernelGGL((fast::frbch_k2c_fast<1, 1024>), grid, dim3(1024), pl.k2c_fast_lds, s, p); break;
+    case 2: hipLaunchKernelGGL((fast::frbch_k2c_fast<2, 1024>), grid, dim3(1024), pl.k2c_fast_lds, s, p); break;
+    case 3: hipLaunchKernelGGL((fast::frbch_k2c_fast<3, 1024>), grid, dim3(1024), pl.k2c_fast_lds, s, p); break;
+    case 4: hipLaunchKernelGGL((fast::frbch_k2c_fast<4, 1024>), grid, dim3(1024), pl.k2c_fast_lds, s, p); break;
+    case 5: hipLaunchKernelGGL((fast::frbch_k2c_fast<5, 1024>), grid, dim3(1024), pl.k2c_fast_lds, s, p); break;
+    default: return false;
+  }
+  return true;
+}
+bool launch_k3_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
+  const Plan& pl = h->pl;
+  if (!pl.coh_fast_r || !h->coh_order_m) return false;
+  const int np = 1024 / (16 << pl.coh_fast_r) / 2;
+  const dim3 grid(pl.c / np, nb);
+  switch (pl.coh_fast_r) {
+    case 1: hipLaunchKernelGGL((fast::frbch_k3_fast<1, 1024>), grid, dim3(1024), pl.k3_fast_lds, s, p); break;
+    case 2: hipLaunchKernelGGL((fast::frbch_k3_fast<2, 1024>), grid, dim3(1024), pl.k3_fast_lds, s, p); break;
+    case 3: hipLaunchKernelGGL((fast::frbch_k3_fast<3, 1024>), grid, dim3(1024), pl.k3_fast_lds, s, p); break;
+    case 4: hipLaunchKernelGGL((fast::frbch_k3_fast<4, 1024>), grid, dim3(1024), pl.k3_fast_lds, s, p); break;
+    case 5: hipLaunchKernelGGL((fast::frbch_k3_fast<5, 1024>), grid, dim3(1024), pl.k3_fast_lds, s, p); break;
+    default: return false;
+  }
+  return true;
+}
 template <class K>
 int allow_lds(frbch_handle* h, K kern, size_t bytes) {
   CHECK_DEV(h, dev_allow_lds(kern, bytes), "LDS size (fast kernel)");
@@ -488,6 +519,28 @@ int setup_fast(frbch_handle* h) {
     }
     if (rc) return rc;
   }
+  if (pl.coh_fast_c) {
+    fft_tables(pl.c2, &t1, &t2);
+    if ((rc = upload_cf(h, &h->ftw1_c, t1)) || (rc = upload_cf(h, &h->ftw2_c, t2))) return rc;
+    switch (pl.coh_fast_c) {
+      case 1: rc = allow_lds(h, fast::frbch_k2c_fast<1, 1024>, pl.k2c_fast_lds); break;
+      case 2: rc = allow_lds(h, fast::frbch_k2c_fast<2, 1024>, pl.k2c_fast_lds); break;
+      case 3: rc = allow_lds(h, fast::frbch_k2c_fast<3, 1024>, pl.k2c_fast_lds); break;
+      case 4: rc = allow_lds(h, fast::frbch_k2c_fast<4, 1024>, pl.k2c_fast_lds); break;
+      default: rc = allow_lds(h, fast::frbch_k2c_fast<5, 1024>, pl.k2c_fast_lds); break;
+    }
+    if (rc) return rc;
+  }
+  if (pl.coh_fast_r) {
+    switch (pl.coh_fast_r) {
+      case 1: rc = allow_lds(h, fast::frbch_k3_fast<1, 1024>, pl.k3_fast_lds); break;
+      case 2: rc = allow_lds(h, fast::frbch_k3_fast<2, 1024>, pl.k3_fast_lds); break;
+      case 3: rc = allow_lds(h, fast::frbch_k3_fast<3, 1024>, pl.k3_fast_lds); break;
+      case 4: rc = allow_lds(h, fast::frbch_k3_fast<4, 1024>, pl.k3_fast_lds); break;
+      default: rc = allow_lds(h, fast::frbch_k3_fast<5, 1024>, pl.k3_fast_lds); break;
+    }
+    if (rc) return rc;
+  }
   if (pl.fast_k2_log2m) {
     fft_tables(pl.c2, &t1, &t2);
     if ((rc = upload_cf(h, &h->ftw1_c, t1)) || (rc = upload_cf(h, &h->ftw2_c, t2))) return rc;
@@ -542,8 +595,30 @@ int setup_fast(frbch_handle* h) {
 bool launch_kc_fast(frbch_handle*, KParams&, uint32_t, dev_stream_t) { return false; }
 bool launch_k1_fast(frbch_handle*, KParams&, uint32_t, dev_stream_t) { return false; }
 bool launch_k2_fast(frbch_handle*, KParams&, uint32_t, dev_stream_t) { return false; }
+bool launch_k2c_fast(frbch_handle*, KParams&, uint32_t, dev_stream_t) { return false; }
+bool launch_k3_fast(frbch_handle*, KParams&, uint32_t, dev_stream_t) { return false; }
 int setup_fast(frbch_handle*) { return FRBCH_OK; }
 #endif
+
+// dedispersion kernel table in the fine-bin order of the K1 / K3 pair in use (order_m = 0: generic, M: register passes)
+int build_chirp(frbch_handle* h, int order_m) {
+  const Plan& pl = h->pl;
+  ChirpParams cp;
+  memset(&cp, 0, sizeof cp);
+  cp.chirp = h->chirp;
+  cp.c = pl.c; cp.c2 = pl.c2; cp.r = pl.r; cp.log2_r = pl.log2_r;
+  cp.usb = h->cfg.bw_mhz > 0 ? 1 : 0;
+  cp.order_m = order_m;
+  const double abw = fabs(h->cfg.bw_mhz);
+  cp.band_edge_mhz = cp.usb ? h->cfg.freq_mhz - abw / 2.0 : h->cfg.freq_mhz + abw / 2.0;
+  cp.df_mhz = abw / pl.c;
+  cp.dm_over_k = h->cfg.dm / kDmDispersion;
+  DEV_LAUNCH(frbch_chirp_build, (pl.n + 255) / 256, 1, 256, 0, h->stream, cp);
+  CHECK_DEV(h, dev_check_launch(), "launch chirp build");
+  CHECK_DEV(h, dev_sync(h->stream), "sync");
+  h->coh_order_m = order_m;
+  return FRBCH_OK;
+}
 
 // K1 + Kc over nb blocks: frames -> spill, P0
 int launch_front(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
@@ -552,7 +627,16 @@ int launch_front(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
     const double bytes = (double)nb * ((double)pl.block_payload_bytes * p.frame_bytes / p.payload_bytes +
                                        (double)pl.n * 8.0 + (double)pl.c2 * 8.0);
     ProfScope ps(h, s, KID_K1, bytes);
-    if (pl.coherent || !launch_k1_fast(h, p, nb, s)) DEV_LAUNCH(frbch_k1_branch, pl.c2 / pl.g, nb, pl.nthreads, pl.k1_lds, s, p);
+    bool done = false;
+    if (!pl.coherent) done = launch_k1_fast(h, p, nb, s);
+    else if (h->coh_order_m) {
+      done = launch_k1_fast(h, p, nb, s);
+      if (!done) {   // a start offset the register kernel cannot gather: from here on the generic K1 / K3 and their bin order
+        const int rc = build_chirp(h, 0);
+        if (rc) return rc;
+      }
+    }
+    if (!done) DEV_LAUNCH(frbch_k1_branch, pl.c2 / pl.g, nb, pl.nthreads, pl.k1_lds, s, p);
   }
   if (!pl.coherent) {
     ProfScope ps(h, s, KID_KC, (double)nb * pl.c2 * 16.0);
@@ -571,11 +655,11 @@ int launch_back(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   if (pl.coherent) {   // K2c (branches -> channels, x kernel), K3 (back to time, detect), K4 (time-major rows)
     {
       ProfScope ps(h, s, KID_K2, (double)nb * (double)pl.n * 24.0);
-      DEV_LAUNCH(frbch_k2c_chirp, pl.r / pl.tt, nb, pl.nthreads, pl.k2_lds, s, p);
+      if (!launch_k2c_fast(h, p, nb, s)) DEV_LAUNCH(frbch_k2c_chirp, pl.r / pl.tt, nb, pl.nthreads, pl.k2_lds, s, p);
     }
     {
       ProfScope ps(h, s, KID_K3, (double)nb * ((double)pl.n * 8.0 + (double)pl.rows_per_block * pl.ncol * 4.0));
-      DEV_LAUNCH(frbch_k3_dedisp, pl.c, nb, pl.nthreads, pl.k3_lds, s, p);
+      if (!launch_k3_fast(h, p, nb, s)) DEV_LAUNCH(frbch_k3_dedisp, pl.c, nb, pl.nthreads, pl.k3_lds, s, p);
     }
     {
       ProfScope ps(h, s, KID_K4, (double)nb * (double)pl.rows_per_block * (pl.ncol * 4.0 + out_b));
@@ -859,19 +943,9 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
     CHECK_DEV(h, dev_malloc((void**)&h->spill2, (size_t)pl.maxb * pl.n * sizeof(cf)), "hipMalloc(spill2)");
     CHECK_DEV(h, dev_malloc((void**)&h->chirp, (size_t)pl.n * sizeof(cf)), "hipMalloc(chirp)");
     CHECK_DEV(h, dev_malloc((void**)&h->ptmp, (size_t)pl.maxb * pl.rows_per_block * pl.ncol * sizeof(float)), "hipMalloc(ptmp)");
-    ChirpParams cp;
-    memset(&cp, 0, sizeof cp);
-    cp.chirp = h->chirp;
-    cp.c = pl.c; cp.c2 = pl.c2; cp.r = pl.r; cp.log2_r = pl.log2_r;
-    cp.usb = h->cfg.bw_mhz > 0 ? 1 : 0;
-    const double abw = fabs(h->cfg.bw_mhz);
-    cp.band_edge_mhz = cp.usb ? h->cfg.freq_mhz - abw / 2.0 : h->cfg.freq_mhz + abw / 2.0;
-    cp.df_mhz = abw / pl.c;
-    cp.dm_over_k = h->cfg.dm / kDmDispersion;
-    DEV_LAUNCH(frbch_chirp_build, (pl.n + 255) / 256, 1, 256, 0, h->stream, cp);
-    CHECK_DEV(h, dev_check_launch(), "launch chirp build");
-    CHECK_DEV(h, dev_sync(h->stream), "sync");
-    h->kname[KID_K2] = "frbch_k2c_chirp";
+    if ((rc = build_chirp(h, pl.coh_fast_r ? (1 << pl.coh_fast_r) : 0))) return rc;
+    h->kname[KID_K2] = pl.coh_fast_c ? "frbch_k2c_fast" : "frbch_k2c_chirp";
+    if (pl.coh_fast_r) h->kname[KID_K3] = "frbch_k3_fast";
   }
   CHECK_DEV(h, dev_malloc((void**)&h->offset, pl.ncol * sizeof(float)), "hipMalloc(offset)");
   CHECK_DEV(h, dev_malloc((void**)&h->scale, pl.ncol * sizeof(float)), "hipMalloc(scale)");

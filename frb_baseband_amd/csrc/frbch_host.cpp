@@ -261,6 +261,42 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
     }
   }
 
+  // coherent pipeline on the register-pass kernels (barrier variants): K1 forward-only + K3 need R = 256*M, K2c needs
+  // 2C = 256*M', M, M' in 2..32; the K1 group (64/M branches) becomes the layout group of the first spill
+  pl->coh_fast_r = pl->coh_fast_c = 0;
+  pl->k2c_fast_lds = pl->k3_fast_lds = 0;
+  if (pl->coherent && !(cfg.flags & 1u) && r >= 512 && r <= 8192 && in_bits == 2 && pl->c >= 4) {
+    const int m = (int)r / 256;
+    const int gfast = 64 / m;
+    const size_t seq = (size_t)r + r / 8 + 8;
+    const size_t lds1 = (size_t)gfast * seq * 8 + (size_t)r * (gfast / 2 ? gfast / 2 : 1);
+    const size_t seq3 = (size_t)r + r / 8 + (m == 32 ? 0 : 8);
+    const int ns = 1024 / (16 * m);                 // sequences per K3 workgroup (pairs of rows)
+    const size_t lds3 = (size_t)ns * seq3 * 8;
+    if (gfast >= 2 && gfast <= pl->c2 && lds1 <= lds_limit && lds3 <= lds_limit && ns >= 2 && pl->c % (ns / 2) == 0 &&
+        (size_t)gfast * seq1 <= lds_limit) {
+      pl->coh_fast_r = ilog2(m);
+      pl->fast_k1_log2m = ilog2(m);
+      pl->fast_k1_wave = 0;
+      pl->fast_k1_kind = 0;
+      pl->fast_k1_g = gfast;
+      pl->g = gfast;
+      pl->k1_lds = (size_t)gfast * seq1;
+      pl->k1_fast_lds = lds1;
+      pl->k3_fast_lds = lds3;
+    }
+  }
+  if (pl->coherent && !(cfg.flags & 2u) && pl->c2 >= 512 && pl->c2 <= 8192 && pl->g >= 2) {
+    const int m = pl->c2 / 256;
+    const size_t seq = (size_t)pl->c2 + pl->c2 / 8 + (m == 32 ? 0 : 8);
+    const int tt = 1024 / (16 * m);
+    const size_t lds = (size_t)tt * seq * 8;
+    if (tt >= 1 && tt <= (int)r && (int)r % tt == 0 && lds <= lds_limit && (tt * pl->g) % 2 == 0 && ((size_t)tt * pl->c2 / 2) % 1024 == 0) {
+      pl->coh_fast_c = ilog2(m);
+      pl->k2c_fast_lds = lds;
+    }
+  }
+
   uint32_t maxb = cfg.max_blocks_per_launch;
   if (!maxb) {
     // big batches amortise launches and let the persistent K1 run many iterations (2 GiB of spill)

@@ -49,6 +49,9 @@ struct Plan {
   int fast_k1_kind;           // M = 8 only: 0 = 8 waves x 8 branches, 1 = 4 waves x 4 branches, 2 = 8 waves x 4 branches (2 waves/seq)
   int fast_k2_nw;             // waves per wave-private K2 workgroup (2 or 4)
   int fast_k1_wave, fast_k2_wave; // 1 = wave-private variant (8 / 4 waves per workgroup), 0 = barrier variant
+  // coherent pipeline (-F C:D) on the register-pass kernels: log2(M) of R (K1 forward-only + K3) and of 2C (K2c); 0 = generic
+  int coh_fast_r, coh_fast_c;
+  size_t k2c_fast_lds, k3_fast_lds;
   double rate_in;             // real samples / s / pol
   double rate_out;            // output rows / s
   double tsamp_s;

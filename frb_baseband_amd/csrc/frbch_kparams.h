@@ -67,8 +67,10 @@ struct KParams {
   int keep;                 // channel samples kept per block, a multiple of tscr
   int stag;                 // K1 wave kernels: priority schedule of the two halves of a workgroup (bit mask, see the kernel)
   uint64_t hop;             // real samples between block starts: N, or 2C*keep with overlap-save
-  cf* spill2;               // [nblk][2C][R]  chirped spectrum P'[k'][j], j axis in bit-reversed position
-  const cf* chirp;          // [2C][R]        Hermitian-extended dedispersion kernel, same order
+  cf* spill2;               // [nblk][2C/4][R][4]  chirped spectrum P'[k'][pos]: groups of 4 channels side by side, so that a
+                            // K2c tile (few positions x all channels) writes 32-byte x tile-width runs; pos = position of
+                            // fine bin j in the order the along-branch transform leaves it (S2_INDEX below)
+  const cf* chirp;          // [2C/4][R][4]   Hermitian-extended dedispersion kernel, same order and layout
   float* ptmp;              // [nblk][nif][C][keep/T]  detected + scrunched power, channel-major
   double* stat_partial;     // fast K2, float power: [workgroup row][ncol][2] running (sum, sum of squares); null = off
   uint64_t stat_limit;      // ... of the rows below this absolute row of power_out (the end of the rescale interval)
@@ -104,10 +106,14 @@ struct ChirpParams {        // frbch_chirp_build: fills KParams::chirp once per 
   cf* chirp;
   int c, c2, r, log2_r;
   int usb;                  // 1 = BW > 0
-  int reserved;
+  int order_m;              // 0: fine bin j sits at its bit-reversed position (generic K1); M > 0: at the position the register
+                            // passes radix 16 x M x 16 leave it: pos = kc*16M + ka*M + kb for j = ka + 16 kb + 16M kc
   double band_edge_mhz;     // sky frequency of baseband 0: lower band edge (USB) / upper band edge (LSB)
   double df_mhz;            // channel width |BW|/C
   double dm_over_k;         // DM / 2.41e-4  [s MHz^2]
 };
+
+// element (channel row, position) of one block of spill2 / of the chirp table; r = freq_res
+#define S2_INDEX(row, pos, r) (((((uint64_t)(row) >> 2) * (uint64_t)(r) + (uint64_t)(pos)) << 2) + (uint64_t)((row) & 3))
 
 #endif
