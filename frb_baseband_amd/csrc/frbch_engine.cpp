@@ -278,7 +278,9 @@ int fused_stat_chunks(const Plan& pl, uint32_t h_flags, int pol_mode) {
   if (pol_mode == 3) return 0;   // (PP+QQ)^2: its square overflows the fp32 partial sums (~1e24 squared)
   if (!pl.fast_k2_log2m || !pl.fast_k2_wave || pl.coherent || (h_flags & (1u << 20))) return 0;
   const int nt = k2_wave_nt(pl, h_flags), cg = (int)(pl.ncol / 4);
-  if (!(cg <= nt && nt % cg == 0)) return 0;
+  if (cg > nt)   // a thread owns cg/nt column groups, one row of sums per workgroup (the MSTAT instantiations: 2C = 2048, two waves per sequence)
+    return (cg % nt == 0 && cg / nt <= 4 && pl.fast_k2_log2m == 3 && !(h_flags & 32u) && pl.fast_k2_nw != 8) ? (int)kFusedStatWgs : 0;
+  if (nt % cg != 0) return 0;
   return (int)kFusedStatWgs * (nt / cg);
 }
 template <int LOG2M>
@@ -312,10 +314,12 @@ void launch_k2_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s, u
   if (LOG2M == 3 && !(h_flags & 32u)) {
     if (pl.fast_k2_nw == 2) {
       if (pm == 2) hipLaunchKernelGGL((fast::frbch_k2_wave<3, 4, 2, 2>), grid2, dim3(256), pl.k2_fast_lds, s, p);
+      else if (pm == 4 && p.stat_partial) hipLaunchKernelGGL((fast::frbch_k2_wave<3, 4, 4, 2, true>), grid2, dim3(256), pl.k2_fast_lds, s, p);
       else if (pm == 4) hipLaunchKernelGGL((fast::frbch_k2_wave<3, 4, 4, 2>), grid2, dim3(256), pl.k2_fast_lds, s, p);
       else hipLaunchKernelGGL((fast::frbch_k2_wave<3, 4, 0, 2>), grid2, dim3(256), pl.k2_fast_lds, s, p);
     } else {
       if (pm == 2) hipLaunchKernelGGL((fast::frbch_k2_wave<3, 8, 2, 2>), grid4, dim3(512), pl.k2_fast_lds, s, p);
+      else if (pm == 4 && p.stat_partial) hipLaunchKernelGGL((fast::frbch_k2_wave<3, 8, 4, 2, true>), grid4, dim3(512), pl.k2_fast_lds, s, p);
       else if (pm == 4) hipLaunchKernelGGL((fast::frbch_k2_wave<3, 8, 4, 2>), grid4, dim3(512), pl.k2_fast_lds, s, p);
       else hipLaunchKernelGGL((fast::frbch_k2_wave<3, 8, 0, 2>), grid4, dim3(512), pl.k2_fast_lds, s, p);
     }
@@ -387,12 +391,26 @@ bool launch_k1_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
     }
     return true;
   }
+  KParams q = p;
+  {   // launch-relative 32-bit addressing where the batch fits (else the kernel divides in 64 bits)
+    const uint64_t fr0 = p.payload_off / p.payload_bytes;
+    const uint64_t rel0 = p.payload_off - fr0 * p.payload_bytes;
+    const uint64_t span = rel0 + (uint64_t)(nb - 1) * pl.block_stride_bytes + pl.block_payload_bytes;
+    if (p.payload_bytes >= 2 && span < (1ull << 32)) {
+      q.frames = p.frames + fr0 * p.frame_bytes;
+      q.rel0 = (uint32_t)rel0;
+      q.payload_off = rel0;
+      set_fastdiv(q);
+    } else {
+      q.div_magic = 0;
+    }
+  }
   switch (pl.fast_k1_log2m) {
-    case 1: launch_k1_fast_t<1>(pl, p, nb, s); break;
-    case 2: launch_k1_fast_t<2>(pl, p, nb, s); break;
-    case 3: launch_k1_fast_t<3>(pl, p, nb, s); break;
-    case 4: launch_k1_fast_t<4>(pl, p, nb, s); break;
-    case 5: launch_k1_fast_t<5>(pl, p, nb, s); break;
+    case 1: launch_k1_fast_t<1>(pl, q, nb, s); break;
+    case 2: launch_k1_fast_t<2>(pl, q, nb, s); break;
+    case 3: launch_k1_fast_t<3>(pl, q, nb, s); break;
+    case 4: launch_k1_fast_t<4>(pl, q, nb, s); break;
+    case 5: launch_k1_fast_t<5>(pl, q, nb, s); break;
     default: return false;
   }
   return true;
@@ -576,6 +594,8 @@ int setup_fast(frbch_handle* h) {
         if (!rc) rc = allow_lds(h, fast::frbch_k2_wave<3, 8, 0, 2>, pl.k2_fast_lds);
         if (!rc) rc = allow_lds(h, fast::frbch_k2_wave<3, 8, 2, 2>, pl.k2_fast_lds);
         if (!rc) rc = allow_lds(h, fast::frbch_k2_wave<3, 8, 4, 2>, pl.k2_fast_lds);
+        if (!rc) rc = allow_lds(h, fast::frbch_k2_wave<3, 4, 4, 2, true>, pl.k2_fast_lds);
+        if (!rc) rc = allow_lds(h, fast::frbch_k2_wave<3, 8, 4, 2, true>, pl.k2_fast_lds);
       }
 #undef FRBCH_ALLOW_L
 #undef FRBCH_ALLOW

@@ -93,10 +93,10 @@ def test_statistics_summed_by_k2_equal_the_separate_pass(hip_lib, ten_seconds):
     raw = ten_seconds[: 8032 * 4000 * 2]                      # 2 s
     d_raw = DeviceBuffer.from_numpy(raw)
     nfr = raw.size // 8032
-    for interval in (10.0, 0.7):
+    for interval, pol in ((10.0, 2), (0.7, 2), (10.0, 4), (0.7, 4)):     # pol 4: a K2 thread owns four column groups
         res = []
         for flags in (0, 1 << 20):
-            cfg = pu.lib_cfg(hip_lib, 32.0, 1024, 2.0, interval=interval, flags=flags)
+            cfg = pu.lib_cfg(hip_lib, 32.0, 1024, 2.0, interval=interval, flags=flags, pol=pol)
             with ch.Channeliser(cfg, hip_lib) as c:
                 info = c.info
                 nblocks = (nfr * 8000) // info.block_payload_bytes
