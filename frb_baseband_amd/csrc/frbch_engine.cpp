@@ -17,6 +17,9 @@
 
 #include <algorithm>
 #include <string>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "frbch_host.h"
@@ -1332,8 +1335,247 @@ bool write_all(int fd, const uint8_t* p, size_t n) {
 }
 }  // namespace
 
+namespace {
+
+// Whole-file path for a regular input file: a reader thread preads the frames of the next batch into one of two pinned
+// buffers while the GPU works on the current one, rows come back through two pinned buffers that a writer thread
+// drains into the output (strictly sequential writes: the target may be a FIFO).  No copy through `carry` / `outq`.
+// Returns FRBCH_OK, an error, or 1 = "not applicable, use the generic stream path" (nothing consumed).
+struct PipeQueue {          // two-slot hand-off between two threads
+  std::mutex m;
+  std::condition_variable cv;
+  int ready[2] = {0, 0};    // slot state: 0 free, 1 filled
+  size_t nbytes[2] = {0, 0};
+  bool stop = false;
+  int error = 0;
+};
+
+int run_file_pipelined(frbch_handle* h, int in_fd, int out_fd) {
+  struct stat st;
+  if (fstat(in_fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 32 || h->have_vdif) return 1;
+  uint8_t first[32];
+  if (pread(in_fd, first, 32, 0) != 32) return 1;
+  int rc = stream_begin(h, first);
+  if (rc) return rc;
+  const Plan& pl = h->pl;
+  const uint64_t fb = h->v0.frame_bytes, hb = h->v0.header_bytes(), pb = h->v0.payload_bytes();
+  const uint64_t nfile = (uint64_t)st.st_size / fb;                       // whole frames in the file
+  const uint64_t pay_total = nfile * pb;
+  uint64_t nblk = 0;
+  if (pay_total >= h->skip_bytes + pl.block_payload_bytes)
+    nblk = (pay_total - h->skip_bytes - pl.block_payload_bytes) / pl.block_stride_bytes + 1;
+  nblk = std::min<uint64_t>(nblk, h->blocks_budget);
+
+  // pinned staging is expensive to allocate (~0.5 ms per MB): small pieces, two of each
+  const size_t in_cap = (size_t)std::max<uint64_t>(fb, ((16u << 20) / fb) * fb), out_cap = 16u << 20;
+  uint8_t* inbuf[2] = {nullptr, nullptr};
+  uint8_t* outbuf[2] = {nullptr, nullptr};
+  auto release = [&]() {
+    for (int i = 0; i < 2; ++i) { dev_host_free(inbuf[i]); dev_host_free(outbuf[i]); }
+  };
+  for (int i = 0; i < 2; ++i)
+    if (dev_host_alloc((void**)&inbuf[i], in_cap) != 0 || dev_host_alloc((void**)&outbuf[i], out_cap) != 0) {
+      release();
+      return fail(h, FRBCH_E_NOMEM, "pinned staging buffers");
+    }
+
+  // batch geometry
+  struct Batch { uint64_t nb, f0, nfr, pay_off; };
+  std::vector<Batch> batches;
+  for (uint64_t b0 = 0; b0 < nblk; b0 += pl.maxb) {
+    Batch b;
+    b.nb = std::min<uint64_t>(pl.maxb, nblk - b0);
+    const uint64_t p0 = h->skip_bytes + b0 * pl.block_stride_bytes;
+    const uint64_t p1 = p0 + (b.nb - 1) * pl.block_stride_bytes + pl.block_payload_bytes;
+    b.f0 = p0 / pb;
+    b.nfr = (p1 + pb - 1) / pb - b.f0;
+    b.pay_off = p0 - b.f0 * pb;
+    batches.push_back(b);
+  }
+
+  // every batch's frames travel in pieces of whole frames that fit a pinned buffer
+  struct Piece { uint64_t f0, nfr; size_t dst_off; };
+  std::vector<Piece> pieces;
+  std::vector<size_t> batch_first_piece;
+  for (const Batch& b : batches) {
+    batch_first_piece.push_back(pieces.size());
+    const uint64_t per = in_cap / fb;
+    for (uint64_t f = 0; f < b.nfr; f += per) pieces.push_back(Piece{b.f0 + f, std::min<uint64_t>(per, b.nfr - f), (size_t)(f * fb)});
+  }
+  batch_first_piece.push_back(pieces.size());
+  PipeQueue qin, qout;
+  std::thread reader([&]() {
+    for (size_t i = 0; i < pieces.size(); ++i) {
+      const int slot = (int)(i & 1);
+      {
+        std::unique_lock<std::mutex> lk(qin.m);
+        qin.cv.wait(lk, [&] { return qin.ready[slot] == 0 || qin.stop; });
+        if (qin.stop) return;
+      }
+      const size_t want = (size_t)(pieces[i].nfr * fb);
+      size_t got = 0;
+      while (got < want) {
+        const ssize_t n = pread(in_fd, inbuf[slot] + got, want - got, (off_t)(pieces[i].f0 * fb + got));
+        if (n < 0 && errno == EINTR) continue;
+        if (n <= 0) break;
+        got += (size_t)n;
+      }
+      std::lock_guard<std::mutex> lk(qin.m);
+      if (got != want) qin.error = errno ? errno : EIO;
+      qin.nbytes[slot] = got;
+      qin.ready[slot] = 1;
+      qin.cv.notify_all();
+      if (qin.error) return;
+    }
+  });
+  std::thread writer([&]() {
+    for (size_t i = 0;; ++i) {
+      const int slot = (int)(i & 1);
+      size_t n;
+      {
+        std::unique_lock<std::mutex> lk(qout.m);
+        qout.cv.wait(lk, [&] { return qout.ready[slot] == 1 || qout.stop; });
+        if (qout.ready[slot] != 1) return;       // stop and nothing pending
+        n = qout.nbytes[slot];
+      }
+      const bool ok = write_all(out_fd, outbuf[slot], n);
+      std::lock_guard<std::mutex> lk(qout.m);
+      if (!ok) qout.error = errno ? errno : EIO;
+      qout.ready[slot] = 0;
+      qout.cv.notify_all();
+      if (!ok) return;
+    }
+  });
+  size_t out_i = 0;                                // next output slot
+  auto out_acquire = [&]() -> int {                // wait until the slot is free; returns slot or -1 on writer error
+    const int slot = (int)(out_i & 1);
+    std::unique_lock<std::mutex> lk(qout.m);
+    qout.cv.wait(lk, [&] { return qout.ready[slot] == 0 || qout.error; });
+    return qout.error ? -1 : slot;
+  };
+  auto out_submit = [&](int slot, size_t n) {
+    std::lock_guard<std::mutex> lk(qout.m);
+    qout.nbytes[slot] = n;
+    qout.ready[slot] = 1;
+    ++out_i;
+    qout.cv.notify_all();
+  };
+  // rows that sit in h->d_out -> pinned buffers -> writer
+  auto emit_rows = [&](uint64_t rows) -> int {
+    const size_t total = (size_t)(rows * pl.row_bytes);
+    for (size_t off = 0; off < total;) {
+      const size_t n = std::min(out_cap, total - off);
+      const int slot = out_acquire();
+      if (slot < 0) return fail(h, FRBCH_E_IO, std::string("write: ") + strerror(qout.error));
+      CHECK_DEV(h, dev_d2h(outbuf[slot], h->d_out + off, n, h->stream), "download rows");
+      CHECK_DEV(h, dev_sync(h->stream), "sync");
+      out_submit(slot, n);
+      off += n;
+    }
+    return FRBCH_OK;
+  };
+
+  {   // SIGPROC header first
+    const std::vector<uint8_t> hdr = sigproc_header(h->cfg, pl, h->tstart_mjd);
+    const int slot = out_acquire();
+    if (slot < 0) rc = fail(h, FRBCH_E_IO, "write");
+    else {
+      memcpy(outbuf[slot], hdr.data(), hdr.size());
+      out_submit(slot, hdr.size());
+    }
+  }
+  const double fps_d = pl.rate_in * 2.0 * pl.in_bits / 8.0 / (double)pb;
+  const uint64_t fps = (uint64_t)llround(fps_d);
+  uint64_t checked_upto = 0;                       // file frame index below which headers were checked
+  for (size_t i = 0; i < batches.size() && !rc; ++i) {
+    const Batch& b = batches[i];
+    for (size_t pi = batch_first_piece[i]; pi < batch_first_piece[i + 1] && !rc; ++pi) {
+    const int slot = (int)(pi & 1);
+    const Piece& pc = pieces[pi];
+    {
+      std::unique_lock<std::mutex> lk(qin.m);
+      qin.cv.wait(lk, [&] { return qin.ready[slot] == 1; });
+      if (qin.error) {
+        rc = fail(h, FRBCH_E_IO, std::string("read: ") + strerror(qin.error));
+        break;
+      }
+    }
+    // header checks (frames shared with the previous batch are not counted twice): as check_headers
+    for (uint64_t f = std::max(pc.f0, checked_upto); f < pc.f0 + pc.nfr && !rc; ++f) {
+      VdifInfo v;
+      parse_vdif_header(inbuf[slot] + (f - pc.f0) * fb, &v);
+      if (v.frame_bytes != h->v0.frame_bytes || v.legacy != h->v0.legacy || v.bits_per_sample != h->v0.bits_per_sample ||
+          v.log2_nchan != h->v0.log2_nchan)
+        rc = fail(h, FRBCH_E_FORMAT, "VDIF frame header changes geometry mid-stream (frame " + std::to_string(f) + ")");
+      const uint64_t idx = (uint64_t)v.seconds * fps + v.frame_nr;
+      if (h->frames_seen && idx != h->next_frame_index) h->frame_gaps++;
+      h->next_frame_index = idx + 1;
+      if (v.invalid) h->frames_invalid++;
+      h->frames_seen++;
+    }
+    checked_upto = std::max(checked_upto, pc.f0 + pc.nfr);
+    if (rc) break;
+    if (dev_h2d(h->d_frames + pc.dst_off, inbuf[slot], (size_t)(pc.nfr * fb), h->stream) != 0 || dev_sync(h->stream) != 0) {
+      rc = fail(h, FRBCH_E_DEVICE, std::string("upload frames: ") + dev_last_error_string());
+      break;
+    }
+    {   // the pinned buffer is free again: the reader may fill it with the piece after next
+      std::lock_guard<std::mutex> lk(qin.m);
+      qin.ready[slot] = 0;
+      qin.cv.notify_all();
+    }
+    }
+    if (rc) break;
+    uint64_t rows = 0;
+    rc = engine_feed(h, h->d_frames, (uint32_t)fb, (uint32_t)hb, b.pay_off, b.nb, h->d_out, h->d_out_cap, &rows, h->stream);
+    if (!rc && rows) rc = emit_rows(rows);
+    h->blocks_budget -= std::min<uint64_t>(h->blocks_budget, b.nb);
+    h->skip_bytes += b.nb * pl.block_stride_bytes;
+  }
+  if (!rc) {
+    uint64_t rows = 0;
+    rc = engine_flush(h, h->d_out, h->d_out_cap, &rows, h->stream);
+    if (!rc && rows) rc = emit_rows(rows);
+  }
+  {   // stop the threads: the reader may be waiting for a slot, the writer for data
+    { std::lock_guard<std::mutex> lk(qin.m); qin.stop = true; qin.cv.notify_all(); }
+    reader.join();
+    {   // let the writer drain what is queued, then stop
+      std::unique_lock<std::mutex> lk(qout.m);
+      qout.cv.wait(lk, [&] { return (qout.ready[0] == 0 && qout.ready[1] == 0) || qout.error; });
+      qout.stop = true;
+      qout.cv.notify_all();
+    }
+    writer.join();
+    if (!rc && qout.error) rc = fail(h, FRBCH_E_IO, std::string("write: ") + strerror(qout.error));
+  }
+  release();
+  return rc;
+}
+
+}  // namespace
+
 extern "C" int frbch_run_file(frbch_handle* h, const char* vdif_path, const char* out_fil) {
   if (!h || !vdif_path || !out_fil) return FRBCH_E_ARG;
+  if (!getenv("FRBCH_NO_PIPELINE")) {   // regular input file: overlapped read / transform / write
+    const int in_fd = open(vdif_path, O_RDONLY);
+    if (in_fd < 0) return fail(h, FRBCH_E_IO, std::string("cannot open ") + vdif_path + ": " + strerror(errno));
+    struct stat st;
+    if (fstat(in_fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= 32 && !h->have_vdif) {
+      // INSTALL.md:32-35: no O_EXCL, so that a pre-made FIFO (base2fil.sh:348-349) can be the target
+      const int out_fd = open(out_fil, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+      if (out_fd < 0) {
+        close(in_fd);
+        return fail(h, FRBCH_E_IO, std::string("cannot open ") + out_fil + ": " + strerror(errno));
+      }
+      int rc = run_file_pipelined(h, in_fd, out_fd);
+      close(in_fd);
+      if (close(out_fd) != 0 && !rc) rc = fail(h, FRBCH_E_IO, std::string("close: ") + strerror(errno));
+      if (rc != 1) return rc;
+    } else {
+      close(in_fd);
+    }
+  }
   FILE* in = fopen(vdif_path, "rb");
   if (!in) return fail(h, FRBCH_E_IO, std::string("cannot open ") + vdif_path + ": " + strerror(errno));
   // INSTALL.md:32-35: no O_EXCL, so that a pre-made FIFO (base2fil.sh:348-349) can be the target

@@ -13,7 +13,7 @@ if not os.path.exists(vd):
         for i in range(int(secs)):
             f.write(one.tobytes())      # repeated second: fine for a rate measurement
 hdr = pv.make_hdr("R3", 1340.49, vd, pol=2, usb=False, ra="01:58:00.75", dec="65:43:00.3", bw=32.0, telescope="effelsberg")
-for backend in ("abi", "shim"):
+for backend in ("abi", "abi", "shim", "shim"):   # the first call of each kind pays HIP initialisation / page-cache warm-up
     t0 = time.perf_counter()
     out = pv.run_digifil(hdr, d, 0, secs, 1024, overwrite=True, pol=2, nbit=8, backend=backend)
     dt = time.perf_counter() - t0
