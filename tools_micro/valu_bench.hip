@@ -7,6 +7,11 @@ __global__ void k_valu(int iters, float* sink, unsigned long long* cyc) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) a[i] = (float)(threadIdx.x + i);
   const float c = 1.0001f, d = 0.5f;
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 pk[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) pk[i] = f2{a[2 * i], a[2 * i + 1]};
+  const f2 pc = {c, c}, pd = {d, d};
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -16,13 +21,16 @@ __global__ void k_valu(int iters, float* sink, unsigned long long* cyc) {
         if (KIND == 0) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(d));
         else if (KIND == 1) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(d));
         else if (KIND == 2) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
-        else asm volatile("v_sub_f32 %0, %1, %0" : "+v"(a[i]) : "v"(d));
+        else if (KIND == 3) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(pk[i & 7]) : "v"(pd));
+        else if (KIND == 4) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(pk[i & 7]) : "v"(pc), "v"(pd));
+        else asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(pk[i & 7]) : "v"(pc));
       }
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
   float s = 0; for (int i = 0; i < 16; ++i) s += a[i];
+  for (int i = 0; i < 8; ++i) s += pk[i].x + pk[i].y;
   if (s == 123.456f) sink[0] = s;
 }
 template <int KIND>
@@ -41,10 +49,12 @@ void run(const char* name, int waves_per_cu, float* sink, unsigned long long* cy
 int main() {
   float* sink; hipMalloc((void**)&sink, 64);
   unsigned long long* cyc; hipMalloc((void**)&cyc, 8192 * 8);
-  for (int w : {4, 8, 16, 32}) {
+  for (int w : {4, 8, 16}) {
     run<0>("v_add_f32", w, sink, cyc);
     run<1>("v_fma_f32", w, sink, cyc);
-    run<2>("v_mul_f32", w, sink, cyc);
+    run<3>("v_pk_add_f32", w, sink, cyc);
+    run<4>("v_pk_fma_f32", w, sink, cyc);
+    run<5>("v_pk_mul_f32", w, sink, cyc);
   }
   return 0;
 }
