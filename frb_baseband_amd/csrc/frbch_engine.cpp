@@ -34,9 +34,9 @@ using namespace frbch;
 
 namespace {
 
-enum { KID_K1 = 0, KID_KC, KID_K2, KID_STATS, KID_QUANT, KID_K3, KID_K4, KID_COUNT };
+enum { KID_K1 = 0, KID_KC, KID_K2, KID_STATS, KID_QUANT, KID_K3, KID_K4, KID_K0, KID_COUNT };
 const char* const kKernelNames[KID_COUNT] = {"frbch_k1_branch", "frbch_kc_dcfix", "frbch_k2_chan",
-                                             "frbch_stats", "frbch_quantise", "frbch_k3_dedisp", "frbch_k4_out"};
+                                             "frbch_stats", "frbch_quantise", "frbch_k3_dedisp", "frbch_k4_out", "frbch_k0_stage"};
 
 struct EventPair {
   dev_event_t a, b;
@@ -92,6 +92,8 @@ struct frbch_handle {
   size_t d_frames_cap = 0;
   uint8_t* d_out = nullptr;
   size_t d_out_cap = 0;
+  uint8_t* stg = nullptr;          // corner-turned payload of one launch batch for the wave K1 (frbch_k0_stage)
+  bool stg_ready = false;          // ... valid for the launch in progress
   std::vector<uint8_t> outq;
   size_t outq_pos = 0;
   // frbch_run_scan: rows go into this IF's columns of a pitched device buffer shared by the IFs of the scan
@@ -249,18 +251,20 @@ void launch_k1_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
   static const uint32_t cap_env = getenv("FRBCH_K1_MAXWG") ? (uint32_t)atoi(getenv("FRBCH_K1_MAXWG")) : 0u;   // experiments
   const uint32_t resident = cap_env ? cap_env : 256u * (uint32_t)std::max<size_t>(1, (160 * 1024) / pl.k1_fast_lds);
   uint32_t ny = std::max<uint32_t>(1, std::min<uint32_t>(nb, resident / std::max<uint32_t>(1, ngrp)));
+#define FRBCH_K1W(L, NWV, WPSV, NTV)                                                                                       \
+  do {                                                                                                                  \
+    if (p.stg) hipLaunchKernelGGL((fast::frbch_k1_wave<L, NWV, WPSV, true>), dim3(ngrp, ny), dim3(NTV), pl.k1_fast_lds, s, p);  \
+    else hipLaunchKernelGGL((fast::frbch_k1_wave<L, NWV, WPSV, false>), dim3(ngrp, ny), dim3(NTV), pl.k1_fast_lds, s, p);        \
+  } while (0)
   if constexpr (LOG2M == 4) {
-    hipLaunchKernelGGL((fast::frbch_k1_wave<4, 8, 2>), dim3(ngrp, ny), dim3(512), pl.k1_fast_lds, s, p);
+    FRBCH_K1W(4, 8, 2, 512);
   } else {
-    if (LOG2M == 3 && pl.fast_k1_kind == 1)
-      hipLaunchKernelGGL((fast::frbch_k1_wave<3, 4, 1>), dim3(ngrp, ny), dim3(256), pl.k1_fast_lds, s, p);
-    else if (LOG2M == 3 && pl.fast_k1_kind == 2)
-      hipLaunchKernelGGL((fast::frbch_k1_wave<3, 8, 2>), dim3(ngrp, ny), dim3(512), pl.k1_fast_lds, s, p);
-    else if (LOG2M == 3 && pl.fast_k1_kind == 3)
-      hipLaunchKernelGGL((fast::frbch_k1_wave<3, 16, 2>), dim3(ngrp, ny), dim3(1024), pl.k1_fast_lds, s, p);
-    else
-      hipLaunchKernelGGL((fast::frbch_k1_wave<LOG2M, 8, 1>), dim3(ngrp, ny), dim3(512), pl.k1_fast_lds, s, p);
+    if (LOG2M == 3 && pl.fast_k1_kind == 1) FRBCH_K1W(3, 4, 1, 256);
+    else if (LOG2M == 3 && pl.fast_k1_kind == 2) FRBCH_K1W(3, 8, 2, 512);
+    else if (LOG2M == 3 && pl.fast_k1_kind == 3) FRBCH_K1W(3, 16, 2, 1024);
+    else FRBCH_K1W(LOG2M, 8, 1, 512);
   }
+#undef FRBCH_K1W
   if (stamp_path && nb > 8 * ny) {
     std::vector<unsigned long long> hst(stamp_n);
     (void)hipStreamSynchronize(s);
@@ -368,6 +372,38 @@ bool launch_kc_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   }
   return true;
 }
+// corner-turn of the batch's payload for the wave K1 (own timing slot); same preconditions as launch_k1_fast
+void launch_k0_stage(frbch_handle* h, const KParams& p, uint32_t nb, dev_stream_t s) {
+  const Plan& pl = h->pl;
+  h->stg_ready = false;
+  static const bool no_k0 = getenv("FRBCH_NO_K0") != nullptr;   // experiments: gather straight from the frames
+  if (!h->stg || no_k0 || !pl.fast_k1_log2m || !pl.fast_k1_wave || pl.coherent || pl.c % 256 != 0 || pl.r % 64 != 0) return;
+  const uint32_t rb = (uint32_t)pl.fast_k1_g / 2;
+  if (p.payload_off % rb || p.payload_bytes % rb || p.header_bytes % rb || p.frame_bytes % rb || ((uintptr_t)p.frames % 16) ||
+      p.payload_bytes < 2 || rb < 2 || p.payload_off % 4 || p.payload_bytes % 4 || p.header_bytes % 4 || p.frame_bytes % 4)
+    return;
+  const uint64_t fr0 = p.payload_off / p.payload_bytes;
+  const uint64_t rel0 = p.payload_off - fr0 * p.payload_bytes;
+  if (rel0 + (uint64_t)nb * pl.block_payload_bytes >= (1ull << 32)) return;
+  KParams q = p;
+  q.frames = p.frames + fr0 * p.frame_bytes;
+  q.rel0 = (uint32_t)rel0;
+  set_fastdiv(q);
+  q.stg_out = h->stg;
+  ProfScope ps(h, s, KID_K0, (double)nb * (double)pl.block_payload_bytes * (1.0 + (double)p.frame_bytes / p.payload_bytes));
+  const dim3 grid((pl.r / 64) * (pl.c / 256), nb);
+  const bool wide = !(rel0 % 16 || p.payload_bytes % 16 || p.header_bytes % 16 || p.frame_bytes % 16);
+#define FRBCH_K0(RBV) do { if (wide) hipLaunchKernelGGL((fast::frbch_k0_stage<RBV, true>), grid, dim3(256), 0, s, q); \
+                           else hipLaunchKernelGGL((fast::frbch_k0_stage<RBV, false>), grid, dim3(256), 0, s, q); } while (0)
+  switch (rb) {
+    case 2: FRBCH_K0(2); break;
+    case 4: FRBCH_K0(4); break;
+    case 8: FRBCH_K0(8); break;
+    default: FRBCH_K0(16); break;
+  }
+#undef FRBCH_K0
+  h->stg_ready = true;
+}
 bool launch_k1_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   const Plan& pl = h->pl;
   if (!pl.fast_k1_log2m) return false;
@@ -385,6 +421,8 @@ bool launch_k1_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
     q.frames = p.frames + fr0 * p.frame_bytes;
     q.rel0 = (uint32_t)rel0;
     set_fastdiv(q);
+    if (h->stg_ready) q.stg = h->stg;   // launch_k0_stage has corner-turned this batch
+    h->stg_ready = false;
     switch (pl.fast_k1_log2m) {
       case 1: launch_k1_wave_t<1>(pl, q, nb, s); break;
       case 2: launch_k1_wave_t<2>(pl, q, nb, s); break;
@@ -520,17 +558,18 @@ int setup_fast(frbch_handle* h) {
       }
     }
     if ((rc = upload_cf(h, &h->td1, d1)) || (rc = upload_cf(h, &h->td2, d2))) return rc;
+    if (pl.fast_k1_wave && !h->stg)
+      CHECK_DEV(h, dev_malloc((void**)&h->stg, (size_t)pl.maxb * pl.block_payload_bytes), "hipMalloc(staged payload)");
+#define FRBCH_AL(L, NWV, WPSV) do { if (!rc) rc = allow_lds(h, fast::frbch_k1_wave<L, NWV, WPSV, false>, pl.k1_fast_lds); \
+                                    if (!rc) rc = allow_lds(h, fast::frbch_k1_wave<L, NWV, WPSV, true>, pl.k1_fast_lds); } while (0)
+    rc = FRBCH_OK;
     if (pl.fast_k1_wave) switch (pl.fast_k1_log2m) {
-      case 1: rc = allow_lds(h, fast::frbch_k1_wave<1, 8, 1>, pl.k1_fast_lds); break;
-      case 2: rc = allow_lds(h, fast::frbch_k1_wave<2, 8, 1>, pl.k1_fast_lds); break;
-      case 4: rc = allow_lds(h, fast::frbch_k1_wave<4, 8, 2>, pl.k1_fast_lds); break;
-      default:
-        rc = allow_lds(h, fast::frbch_k1_wave<3, 8, 1>, pl.k1_fast_lds);
-        if (!rc) rc = allow_lds(h, fast::frbch_k1_wave<3, 4, 1>, pl.k1_fast_lds);
-        if (!rc) rc = allow_lds(h, fast::frbch_k1_wave<3, 8, 2>, pl.k1_fast_lds);
-        if (!rc) rc = allow_lds(h, fast::frbch_k1_wave<3, 16, 2>, pl.k1_fast_lds);
-        break;
+      case 1: FRBCH_AL(1, 8, 1); break;
+      case 2: FRBCH_AL(2, 8, 1); break;
+      case 4: FRBCH_AL(4, 8, 2); break;
+      default: FRBCH_AL(3, 8, 1); FRBCH_AL(3, 4, 1); FRBCH_AL(3, 8, 2); FRBCH_AL(3, 16, 2); break;
     }
+#undef FRBCH_AL
     else switch (pl.fast_k1_log2m) {
       case 1: rc = allow_lds(h, fast::frbch_k1_fast<1>, pl.k1_fast_lds); break;
       case 2: rc = allow_lds(h, fast::frbch_k1_fast<2>, pl.k1_fast_lds); break;
@@ -618,6 +657,7 @@ int setup_fast(frbch_handle* h) {
 bool launch_kc_fast(frbch_handle*, KParams&, uint32_t, dev_stream_t) { return false; }
 bool launch_k1_fast(frbch_handle*, KParams&, uint32_t, dev_stream_t) { return false; }
 bool launch_k2_fast(frbch_handle*, KParams&, uint32_t, dev_stream_t) { return false; }
+void launch_k0_stage(frbch_handle*, const KParams&, uint32_t, dev_stream_t) {}
 bool launch_k2c_fast(frbch_handle*, KParams&, uint32_t, dev_stream_t) { return false; }
 bool launch_k3_fast(frbch_handle*, KParams&, uint32_t, dev_stream_t) { return false; }
 int setup_fast(frbch_handle*) { return FRBCH_OK; }
@@ -647,6 +687,7 @@ int build_chirp(frbch_handle* h, int order_m) {
 int launch_front(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   const Plan& pl = h->pl;
   {
+    launch_k0_stage(h, p, nb, s);
     const double bytes = (double)nb * ((double)pl.block_payload_bytes * p.frame_bytes / p.payload_bytes +
                                        (double)pl.n * 8.0 + (double)pl.c2 * 8.0);
     ProfScope ps(h, s, KID_K1, bytes);
@@ -989,7 +1030,7 @@ extern "C" void frbch_close(frbch_handle* h) {
   dev_free(h->spill); dev_free(h->s_dc); dev_free(h->p0);
   dev_free(h->spill2); dev_free(h->chirp); dev_free(h->ptmp);
   dev_free(h->offset); dev_free(h->scale); dev_free(h->powbuf); dev_free(h->partial);
-  dev_free(h->d_frames); dev_free(h->d_out);
+  dev_free(h->d_frames); dev_free(h->d_out); dev_free(h->stg);
   if (h->stream) dev_stream_destroy(h->stream);
   delete h;
 }

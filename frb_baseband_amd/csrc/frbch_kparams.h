@@ -76,6 +76,9 @@ struct KParams {
   uint64_t stat_limit;      // ... of the rows below this absolute row of power_out (the end of the rescale interval)
   uint32_t nblk;            // blocks in this launch (persistent kernels loop over them)
   uint32_t dbg;             // timing-only ablations (cfg.flags >> 8); results are wrong when set
+  const uint8_t* stg;        // wave K1: the launch's payload re-ordered by frbch_k0_stage, [blk][branch group][row][RB bytes]: the
+                             // rows of one workgroup and block are contiguous (null = gather from the frames)
+  uint8_t* stg_out;          // frbch_k0_stage: where it writes that buffer
   unsigned long long* stamps; // diagnostic builds of the wave K1: s_memtime stamps [workgroup][wave][16] of one block; null = off
 };
 
