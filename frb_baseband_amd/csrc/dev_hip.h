@@ -64,6 +64,9 @@ static inline int dev_copy2d(void* d, size_t dpitch, const void* s_, size_t spit
 static inline int dev_memset(void* d, int v, size_t n, dev_stream_t s) {
   return hipMemsetAsync(d, v, n, s) == hipSuccess ? 0 : -1;
 }
+static inline int dev_memset32(void* d, uint32_t v, size_t nwords, dev_stream_t s) {
+  return hipMemsetD32Async((hipDeviceptr_t)d, (int)v, nwords, s) == hipSuccess ? 0 : -1;
+}
 static inline int dev_sync(dev_stream_t s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
 static inline int dev_stream_create(dev_stream_t* s) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking) == hipSuccess ? 0 : -1; }
 static inline void dev_stream_destroy(dev_stream_t s) { (void)hipStreamDestroy(s); }

@@ -929,10 +929,9 @@ int engine_flush(frbch_handle* h, uint8_t* d_out, size_t cap, uint64_t* rows_wri
 
 int set_identity_rescale(frbch_handle* h) {
   const Plan& pl = h->pl;
-  std::vector<float> zero(pl.ncol, 0.0f), one(pl.ncol, 1.0f);
-  CHECK_DEV(h, dev_h2d(h->offset, zero.data(), pl.ncol * sizeof(float), h->stream), "upload offset");
-  CHECK_DEV(h, dev_h2d(h->scale, one.data(), pl.ncol * sizeof(float), h->stream), "upload scale");
-  CHECK_DEV(h, dev_sync(h->stream), "sync");
+  CHECK_DEV(h, dev_memset32(h->offset, 0u, pl.ncol, h->stream), "clear offset");
+  CHECK_DEV(h, dev_memset32(h->scale, 0x3F800000u, pl.ncol, h->stream), "unit scale");     // 1.0f
+  CHECK_DEV(h, dev_sync(h->stream), "sync");   // callers may continue on another stream
   return FRBCH_OK;
 }
 

@@ -58,6 +58,10 @@ static inline int dev_copy2d(void* d, size_t dpitch, const void* s, size_t spitc
   return 0;
 }
 static inline int dev_memset(void* d, int v, size_t n, dev_stream_t) { memset(d, v, n); return 0; }
+static inline int dev_memset32(void* d, uint32_t v, size_t nwords, dev_stream_t) {
+  for (size_t i = 0; i < nwords; ++i) ((uint32_t*)d)[i] = v;
+  return 0;
+}
 static inline int dev_sync(dev_stream_t) { return 0; }
 static inline int dev_stream_create(dev_stream_t* s) { *s = (void*)1; return 0; }
 static inline void dev_stream_destroy(dev_stream_t) {}
