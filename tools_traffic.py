@@ -8,9 +8,9 @@ import sys
 
 src, blocks, tag = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 raw = json.load(open(src))
-if blocks <= 0:   # derive from the K1 dispatch count: 3 launches (64 + 64 + 24 blocks) per 152-block pass
+if blocks <= 0:   # derive from the K1 dispatch count: one launch per 152-block pass (the default batch holds 256 blocks)
     k1 = [v for k, v in raw.items() if "k1_" in k][0]
-    blocks = k1["dispatches"] // 3 * 152
+    blocks = k1["dispatches"] * 152
 out = {"note": "HBM traffic per filterbank block from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes). "
                "FETCH_SIZE is doubled for kernels that stream with 16-B-per-lane loads (gfx950 reports half, "
                "MI355X_MICROARCH.md 'HBM'); the 4-byte-per-lane gather of an unstaged K1 is left uncorrected (uncalibrated width).",
