@@ -377,14 +377,15 @@ void launch_k0_stage(frbch_handle* h, const KParams& p, uint32_t nb, dev_stream_
   const Plan& pl = h->pl;
   h->stg_ready = false;
   static const bool no_k0 = getenv("FRBCH_NO_K0") != nullptr;   // experiments: gather straight from the frames
-  if (!h->stg || no_k0 || !pl.fast_k1_log2m || !pl.fast_k1_wave || pl.coherent || pl.c % 256 != 0 || pl.r % 64 != 0) return;
-  const uint32_t rb = (uint32_t)pl.fast_k1_g / 2;
-  if (p.payload_off % rb || p.payload_bytes % rb || p.header_bytes % rb || p.frame_bytes % rb || ((uintptr_t)p.frames % 16) ||
-      p.payload_bytes < 2 || rb < 2 || p.payload_off % 4 || p.payload_bytes % 4 || p.header_bytes % 4 || p.frame_bytes % 4)
+  if (!h->stg || no_k0 || !pl.fast_k1_log2m || pl.c % 256 != 0 || pl.r % 64 != 0) return;
+  if (pl.coherent && !h->coh_order_m) return;              // the generic K1 is in use
+  const uint32_t rb = (uint32_t)(pl.fast_k1_wave ? pl.fast_k1_g : pl.g) / 2;
+  if (rb < 1 || p.payload_off % rb || p.payload_bytes % rb || p.header_bytes % rb || p.frame_bytes % rb || ((uintptr_t)p.frames % 16) ||
+      p.payload_bytes < 2 || p.payload_off % 4 || p.payload_bytes % 4 || p.header_bytes % 4 || p.frame_bytes % 4)
     return;
   const uint64_t fr0 = p.payload_off / p.payload_bytes;
   const uint64_t rel0 = p.payload_off - fr0 * p.payload_bytes;
-  if (rel0 + (uint64_t)nb * pl.block_payload_bytes >= (1ull << 32)) return;
+  if (rel0 + (uint64_t)(nb - 1) * pl.block_stride_bytes + pl.block_payload_bytes >= (1ull << 32)) return;
   KParams q = p;
   q.frames = p.frames + fr0 * p.frame_bytes;
   q.rel0 = (uint32_t)rel0;
@@ -396,6 +397,7 @@ void launch_k0_stage(frbch_handle* h, const KParams& p, uint32_t nb, dev_stream_
 #define FRBCH_K0(RBV) do { if (wide) hipLaunchKernelGGL((fast::frbch_k0_stage<RBV, true>), grid, dim3(256), 0, s, q); \
                            else hipLaunchKernelGGL((fast::frbch_k0_stage<RBV, false>), grid, dim3(256), 0, s, q); } while (0)
   switch (rb) {
+    case 1: FRBCH_K0(1); break;
     case 2: FRBCH_K0(2); break;
     case 4: FRBCH_K0(4); break;
     case 8: FRBCH_K0(8); break;
@@ -433,6 +435,8 @@ bool launch_k1_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
     return true;
   }
   KParams q = p;
+  if (h->stg_ready) q.stg = h->stg;   // launch_k0_stage has corner-turned this batch
+  h->stg_ready = false;
   {   // launch-relative 32-bit addressing where the batch fits (else the kernel divides in 64 bits)
     const uint64_t fr0 = p.payload_off / p.payload_bytes;
     const uint64_t rel0 = p.payload_off - fr0 * p.payload_bytes;
@@ -558,7 +562,7 @@ int setup_fast(frbch_handle* h) {
       }
     }
     if ((rc = upload_cf(h, &h->td1, d1)) || (rc = upload_cf(h, &h->td2, d2))) return rc;
-    if (pl.fast_k1_wave && !h->stg)
+    if (!h->stg)
       CHECK_DEV(h, dev_malloc((void**)&h->stg, (size_t)pl.maxb * pl.block_payload_bytes), "hipMalloc(staged payload)");
 #define FRBCH_AL(L, NWV, WPSV) do { if (!rc) rc = allow_lds(h, fast::frbch_k1_wave<L, NWV, WPSV, false>, pl.k1_fast_lds); \
                                     if (!rc) rc = allow_lds(h, fast::frbch_k1_wave<L, NWV, WPSV, true>, pl.k1_fast_lds); } while (0)
