@@ -23,7 +23,10 @@ __global__ void k_valu(int iters, float* sink, unsigned long long* cyc) {
         else if (KIND == 2) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
         else if (KIND == 3) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(pk[i & 7]) : "v"(pd));
         else if (KIND == 4) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(pk[i & 7]) : "v"(pc), "v"(pd));
-        else asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(pk[i & 7]) : "v"(pc));
+        else if (KIND == 5) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(pk[i & 7]) : "v"(pc));
+        else if (KIND == 6) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[0]) : "v"(c), "v"(d));        // one dependent chain
+        else if (KIND == 7) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i & 1]) : "v"(c), "v"(d));    // two chains
+        else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i & 3]) : "v"(c), "v"(d));                    // four chains
       }
     }
   }
@@ -55,6 +58,9 @@ int main() {
     run<3>("v_pk_add_f32", w, sink, cyc);
     run<4>("v_pk_fma_f32", w, sink, cyc);
     run<5>("v_pk_mul_f32", w, sink, cyc);
+    run<6>("fma 1 chain", w, sink, cyc);
+    run<7>("fma 2 chains", w, sink, cyc);
+    run<8>("fma 4 chains", w, sink, cyc);
   }
   return 0;
 }
