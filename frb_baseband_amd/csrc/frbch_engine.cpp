@@ -867,8 +867,10 @@ int engine_feed(frbch_handle* h, const uint8_t* d_frames, uint32_t frame_bytes, 
                 dev_stream_t s) {
   const Plan& pl = h->pl;
   *rows_written = 0;
-  for (uint64_t b0 = 0; b0 < nblocks; b0 += pl.maxb) {
-    const uint32_t nb = (uint32_t)std::min<uint64_t>(pl.maxb, nblocks - b0);
+  const uint64_t nbatch = (nblocks + pl.maxb - 1) / pl.maxb;
+  const uint64_t per = nbatch ? (nblocks + nbatch - 1) / nbatch : 0;      // equal batches: no short tail launch
+  for (uint64_t b0 = 0; b0 < nblocks; b0 += per) {
+    const uint32_t nb = (uint32_t)std::min<uint64_t>(per, nblocks - b0);
     KParams p = base_params(h);
     p.frames = d_frames;
     p.frame_bytes = frame_bytes;
@@ -1394,24 +1396,50 @@ struct PipeQueue {          // two-slot hand-off between two threads
   int error = 0;
 };
 
-int run_file_pipelined(frbch_handle* h, int in_fd, int out_fd) {
-  struct stat st;
-  if (fstat(in_fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 32 || h->have_vdif) return 1;
-  uint8_t first[32];
-  if (pread(in_fd, first, 32, 0) != 32) return 1;
-  int rc = stream_begin(h, first);
-  if (rc) return rc;
-  const Plan& pl = h->pl;
-  const uint64_t fb = h->v0.frame_bytes, hb = h->v0.header_bytes(), pb = h->v0.payload_bytes();
-  const uint64_t nfile = (uint64_t)st.st_size / fb;                       // whole frames in the file
-  const uint64_t pay_total = nfile * pb;
-  uint64_t nblk = 0;
-  if (pay_total >= h->skip_bytes + pl.block_payload_bytes)
-    nblk = (pay_total - h->skip_bytes - pl.block_payload_bytes) / pl.block_stride_bytes + 1;
-  nblk = std::min<uint64_t>(nblk, h->blocks_budget);
+// hs: one handle (rows come out of its own staging area) or the IFs of a scan (d_rows != null: every handle's rows go
+// into its columns of the pitched buffer d_rows through its sink, rows every IF has delivered are written).
+int run_pipelined(frbch_handle* const* hs, uint32_t nif, const int* in_fds, int out_fd, uint8_t* d_rows, size_t row_pitch) {
+  frbch_handle* h0 = hs[0];
+  const bool scan = d_rows != nullptr;
+  struct Batch { uint64_t nb, f0, nfr, pay_off; };
+  std::vector<std::vector<Batch>> batches(nif);
+  uint64_t fbmax = 0;
+  for (uint32_t i = 0; i < nif; ++i) {
+    frbch_handle* h = hs[i];
+    struct stat st;
+    if (fstat(in_fds[i], &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 32 || h->have_vdif) return i == 0 ? 1 : fail(h0, FRBCH_E_IO, "scan inputs must all be regular files");
+    uint8_t first[32];
+    if (pread(in_fds[i], first, 32, 0) != 32) return i == 0 ? 1 : fail(h0, FRBCH_E_IO, "short read");
+    const int rc0 = stream_begin(h, first);
+    if (rc0) return h == h0 ? rc0 : fail(h0, rc0, std::string("IF ") + std::to_string(i) + ": " + h->err);
+    const Plan& pl = h->pl;
+    const uint64_t fb = h->v0.frame_bytes, pb = h->v0.payload_bytes();
+    fbmax = std::max(fbmax, fb);
+    const uint64_t nfile = (uint64_t)st.st_size / fb;                       // whole frames in the file
+    const uint64_t pay_total = nfile * pb;
+    uint64_t nblk = 0;
+    if (pay_total >= h->skip_bytes + pl.block_payload_bytes)
+      nblk = (pay_total - h->skip_bytes - pl.block_payload_bytes) / pl.block_stride_bytes + 1;
+    nblk = std::min<uint64_t>(nblk, h->blocks_budget);
+    const uint64_t nbatch = (nblk + pl.maxb - 1) / pl.maxb;
+    const uint64_t per = nbatch ? (nblk + nbatch - 1) / nbatch : 1;       // equal batches
+    for (uint64_t b0 = 0; b0 < nblk; b0 += per) {
+      Batch b;
+      b.nb = std::min<uint64_t>(per, nblk - b0);
+      const uint64_t p0 = h->skip_bytes + b0 * pl.block_stride_bytes;
+      const uint64_t p1 = p0 + (b.nb - 1) * pl.block_stride_bytes + pl.block_payload_bytes;
+      b.f0 = p0 / pb;
+      b.nfr = (p1 + pb - 1) / pb - b.f0;
+      b.pay_off = p0 - b.f0 * pb;
+      batches[i].push_back(b);
+    }
+  }
+  const Plan& pl0 = h0->pl;
+  int rc = FRBCH_OK;
 
   // pinned staging is expensive to allocate (~0.5 ms per MB): small pieces, two of each
-  const size_t in_cap = (size_t)std::max<uint64_t>(fb, ((16u << 20) / fb) * fb), out_cap = 16u << 20;
+  const size_t in_cap = (size_t)std::max<uint64_t>(fbmax, ((16u << 20) / fbmax) * fbmax);
+  const size_t out_cap = std::max<size_t>(16u << 20, scan ? row_pitch : 0);
   uint8_t* inbuf[2] = {nullptr, nullptr};
   uint8_t* outbuf[2] = {nullptr, nullptr};
   auto release = [&]() {
@@ -1420,33 +1448,26 @@ int run_file_pipelined(frbch_handle* h, int in_fd, int out_fd) {
   for (int i = 0; i < 2; ++i)
     if (dev_host_alloc((void**)&inbuf[i], in_cap) != 0 || dev_host_alloc((void**)&outbuf[i], out_cap) != 0) {
       release();
-      return fail(h, FRBCH_E_NOMEM, "pinned staging buffers");
+      return fail(h0, FRBCH_E_NOMEM, "pinned staging buffers");
     }
 
-  // batch geometry
-  struct Batch { uint64_t nb, f0, nfr, pay_off; };
-  std::vector<Batch> batches;
-  for (uint64_t b0 = 0; b0 < nblk; b0 += pl.maxb) {
-    Batch b;
-    b.nb = std::min<uint64_t>(pl.maxb, nblk - b0);
-    const uint64_t p0 = h->skip_bytes + b0 * pl.block_stride_bytes;
-    const uint64_t p1 = p0 + (b.nb - 1) * pl.block_stride_bytes + pl.block_payload_bytes;
-    b.f0 = p0 / pb;
-    b.nfr = (p1 + pb - 1) / pb - b.f0;
-    b.pay_off = p0 - b.f0 * pb;
-    batches.push_back(b);
+  // every batch's frames travel in pieces of whole frames that fit a pinned buffer; batch rounds go IF by IF
+  struct Piece { uint32_t ifx; size_t batch; uint64_t f0, nfr; size_t dst_off; bool ends_batch, ends_round; };
+  std::vector<Piece> pieces;
+  size_t nround = 0;
+  for (uint32_t i = 0; i < nif; ++i) nround = std::max(nround, batches[i].size());
+  for (size_t r = 0; r < nround; ++r) {
+    for (uint32_t i = 0; i < nif; ++i) {
+      if (r >= batches[i].size()) continue;
+      const Batch& b = batches[i][r];
+      const uint64_t fb = hs[i]->v0.frame_bytes;
+      const uint64_t per = in_cap / fb;
+      for (uint64_t f = 0; f < b.nfr; f += per)
+        pieces.push_back(Piece{i, r, b.f0 + f, std::min<uint64_t>(per, b.nfr - f), (size_t)(f * fb), f + per >= b.nfr, false});
+    }
+    if (!pieces.empty()) pieces.back().ends_round = true;
   }
 
-  // every batch's frames travel in pieces of whole frames that fit a pinned buffer
-  struct Piece { uint64_t f0, nfr; size_t dst_off; };
-  std::vector<Piece> pieces;
-  std::vector<size_t> batch_first_piece;
-  for (const Batch& b : batches) {
-    batch_first_piece.push_back(pieces.size());
-    const uint64_t per = in_cap / fb;
-    for (uint64_t f = 0; f < b.nfr; f += per) pieces.push_back(Piece{b.f0 + f, std::min<uint64_t>(per, b.nfr - f), (size_t)(f * fb)});
-  }
-  batch_first_piece.push_back(pieces.size());
   PipeQueue qin, qout;
   std::thread reader([&]() {
     for (size_t i = 0; i < pieces.size(); ++i) {
@@ -1456,10 +1477,11 @@ int run_file_pipelined(frbch_handle* h, int in_fd, int out_fd) {
         qin.cv.wait(lk, [&] { return qin.ready[slot] == 0 || qin.stop; });
         if (qin.stop) return;
       }
+      const uint64_t fb = hs[pieces[i].ifx]->v0.frame_bytes;
       const size_t want = (size_t)(pieces[i].nfr * fb);
       size_t got = 0;
       while (got < want) {
-        const ssize_t n = pread(in_fd, inbuf[slot] + got, want - got, (off_t)(pieces[i].f0 * fb + got));
+        const ssize_t n = pread(in_fds[pieces[i].ifx], inbuf[slot] + got, want - got, (off_t)(pieces[i].f0 * fb + got));
         if (n < 0 && errno == EINTR) continue;
         if (n <= 0) break;
         got += (size_t)n;
@@ -1504,63 +1526,90 @@ int run_file_pipelined(frbch_handle* h, int in_fd, int out_fd) {
     ++out_i;
     qout.cv.notify_all();
   };
-  // rows that sit in h->d_out -> pinned buffers -> writer
-  auto emit_rows = [&](uint64_t rows) -> int {
-    const size_t total = (size_t)(rows * pl.row_bytes);
+  // `total` bytes at device address `src` -> pinned buffers -> writer
+  auto emit_bytes = [&](const uint8_t* src, size_t total, dev_stream_t st) -> int {
     for (size_t off = 0; off < total;) {
       const size_t n = std::min(out_cap, total - off);
       const int slot = out_acquire();
-      if (slot < 0) return fail(h, FRBCH_E_IO, std::string("write: ") + strerror(qout.error));
-      CHECK_DEV(h, dev_d2h(outbuf[slot], h->d_out + off, n, h->stream), "download rows");
-      CHECK_DEV(h, dev_sync(h->stream), "sync");
+      if (slot < 0) return fail(h0, FRBCH_E_IO, std::string("write: ") + strerror(qout.error));
+      CHECK_DEV(h0, dev_d2h(outbuf[slot], src + off, n, st), "download rows");
+      CHECK_DEV(h0, dev_sync(st), "sync");
       out_submit(slot, n);
       off += n;
     }
     return FRBCH_OK;
   };
+  // scan: write the rows every IF has delivered, keep the rest at the top of the buffer (cf. frbch_run_scan)
+  auto drain_scan = [&](bool final_) -> int {
+    uint64_t n = UINT64_MAX;
+    for (uint32_t i = 0; i < nif; ++i) n = std::min(n, hs[i]->sink_rows);
+    if (n && n != UINT64_MAX) {
+      for (uint32_t i = 0; i < nif; ++i) CHECK_DEV(h0, dev_sync(hs[i]->stream), "sync");
+      const int rc1 = emit_bytes(d_rows, (size_t)(n * row_pitch), h0->stream);
+      if (rc1) return rc1;
+    }
+    if (final_) return FRBCH_OK;
+    const size_t seg = pl0.row_bytes / pl0.nif, line_pitch = row_pitch / pl0.nif;
+    for (uint32_t i = 0; i < nif; ++i) {
+      frbch_handle* h = hs[i];
+      const uint64_t left = h->sink_rows - n;
+      if (left && n) {
+        if (left * h->pl.row_bytes > h->d_out_cap) return fail(h0, FRBCH_E_CAPACITY, "scan backlog exceeds the staging area");
+        CHECK_DEV(h0, dev_copy2d(h->d_out, seg, h->sink + n * pl0.nif * line_pitch, line_pitch, seg, left * pl0.nif, h->stream), "move backlog");
+        CHECK_DEV(h0, dev_copy2d(h->sink, line_pitch, h->d_out, seg, seg, left * pl0.nif, h->stream), "move backlog");
+        CHECK_DEV(h0, dev_sync(h->stream), "sync");
+      }
+      h->sink_rows = left;
+    }
+    return FRBCH_OK;
+  };
 
   {   // SIGPROC header first
-    const std::vector<uint8_t> hdr = sigproc_header(h->cfg, pl, h->tstart_mjd);
-    const int slot = out_acquire();
-    if (slot < 0) rc = fail(h, FRBCH_E_IO, "write");
+    if (scan)
+      for (uint32_t i = 1; i < nif && !rc; ++i)
+        if (fabs(hs[i]->tstart_mjd - h0->tstart_mjd) > 0.5 * pl0.tsamp_s / 86400.0)
+          rc = fail(h0, FRBCH_E_FORMAT, "the IFs of the scan do not start at the same time");
+    const std::vector<uint8_t> hdr = sigproc_header(h0->cfg, pl0, h0->tstart_mjd, scan ? (int)(pl0.c * nif) : 0);
+    const int slot = rc ? -1 : out_acquire();
+    if (slot < 0) { if (!rc) rc = fail(h0, FRBCH_E_IO, "write"); }
     else {
       memcpy(outbuf[slot], hdr.data(), hdr.size());
       out_submit(slot, hdr.size());
     }
   }
-  const double fps_d = pl.rate_in * 2.0 * pl.in_bits / 8.0 / (double)pb;
-  const uint64_t fps = (uint64_t)llround(fps_d);
-  uint64_t checked_upto = 0;                       // file frame index below which headers were checked
-  for (size_t i = 0; i < batches.size() && !rc; ++i) {
-    const Batch& b = batches[i];
-    for (size_t pi = batch_first_piece[i]; pi < batch_first_piece[i + 1] && !rc; ++pi) {
+  std::vector<uint64_t> checked_upto(nif, 0);      // file frame index below which headers were checked
+  for (size_t pi = 0; pi < pieces.size() && !rc; ++pi) {
     const int slot = (int)(pi & 1);
     const Piece& pc = pieces[pi];
+    frbch_handle* h = hs[pc.ifx];
+    const Plan& pl = h->pl;
+    const uint64_t fb = h->v0.frame_bytes, hb = h->v0.header_bytes(), pb = h->v0.payload_bytes();
     {
       std::unique_lock<std::mutex> lk(qin.m);
       qin.cv.wait(lk, [&] { return qin.ready[slot] == 1; });
       if (qin.error) {
-        rc = fail(h, FRBCH_E_IO, std::string("read: ") + strerror(qin.error));
+        rc = fail(h0, FRBCH_E_IO, std::string("read: ") + strerror(qin.error));
         break;
       }
     }
     // header checks (frames shared with the previous batch are not counted twice): as check_headers
-    for (uint64_t f = std::max(pc.f0, checked_upto); f < pc.f0 + pc.nfr && !rc; ++f) {
+    const uint64_t fps = (uint64_t)llround(pl.rate_in * 2.0 * pl.in_bits / 8.0 / (double)pb);
+    for (uint64_t f = std::max(pc.f0, checked_upto[pc.ifx]); f < pc.f0 + pc.nfr && !rc; ++f) {
       VdifInfo v;
       parse_vdif_header(inbuf[slot] + (f - pc.f0) * fb, &v);
       if (v.frame_bytes != h->v0.frame_bytes || v.legacy != h->v0.legacy || v.bits_per_sample != h->v0.bits_per_sample ||
           v.log2_nchan != h->v0.log2_nchan)
-        rc = fail(h, FRBCH_E_FORMAT, "VDIF frame header changes geometry mid-stream (frame " + std::to_string(f) + ")");
+        rc = fail(h0, FRBCH_E_FORMAT, "VDIF frame header changes geometry mid-stream (frame " + std::to_string(f) + ")");
       const uint64_t idx = (uint64_t)v.seconds * fps + v.frame_nr;
       if (h->frames_seen && idx != h->next_frame_index) h->frame_gaps++;
       h->next_frame_index = idx + 1;
       if (v.invalid) h->frames_invalid++;
       h->frames_seen++;
     }
-    checked_upto = std::max(checked_upto, pc.f0 + pc.nfr);
+    checked_upto[pc.ifx] = std::max(checked_upto[pc.ifx], pc.f0 + pc.nfr);
     if (rc) break;
     if (dev_h2d(h->d_frames + pc.dst_off, inbuf[slot], (size_t)(pc.nfr * fb), h->stream) != 0 || dev_sync(h->stream) != 0) {
-      rc = fail(h, FRBCH_E_DEVICE, std::string("upload frames: ") + dev_last_error_string());
+      rc = fail(h0, FRBCH_E_DEVICE, std::string("upload frames: ") + dev_last_error_string());
       break;
     }
     {   // the pinned buffer is free again: the reader may fill it with the piece after next
@@ -1568,19 +1617,25 @@ int run_file_pipelined(frbch_handle* h, int in_fd, int out_fd) {
       qin.ready[slot] = 0;
       qin.cv.notify_all();
     }
+    if (pc.ends_batch) {
+      const Batch& b = batches[pc.ifx][pc.batch];
+      uint64_t rows = 0;
+      rc = engine_feed(h, h->d_frames, (uint32_t)fb, (uint32_t)hb, b.pay_off, b.nb, h->d_out, h->d_out_cap, &rows, h->stream);
+      if (rc && h != h0) fail(h0, rc, std::string("IF ") + std::to_string(pc.ifx) + ": " + h->err);
+      if (!rc && rows) rc = scan ? queue_rows(h, rows) : emit_bytes(h->d_out, (size_t)(rows * pl.row_bytes), h->stream);
+      h->blocks_budget -= std::min<uint64_t>(h->blocks_budget, b.nb);
+      h->skip_bytes += b.nb * pl.block_stride_bytes;
     }
-    if (rc) break;
-    uint64_t rows = 0;
-    rc = engine_feed(h, h->d_frames, (uint32_t)fb, (uint32_t)hb, b.pay_off, b.nb, h->d_out, h->d_out_cap, &rows, h->stream);
-    if (!rc && rows) rc = emit_rows(rows);
-    h->blocks_budget -= std::min<uint64_t>(h->blocks_budget, b.nb);
-    h->skip_bytes += b.nb * pl.block_stride_bytes;
+    if (!rc && scan && pc.ends_round) rc = drain_scan(false);
   }
-  if (!rc) {
+  for (uint32_t i = 0; i < nif && !rc; ++i) {
+    frbch_handle* h = hs[i];
     uint64_t rows = 0;
     rc = engine_flush(h, h->d_out, h->d_out_cap, &rows, h->stream);
-    if (!rc && rows) rc = emit_rows(rows);
+    if (rc && h != h0) fail(h0, rc, std::string("IF ") + std::to_string(i) + ": " + h->err);
+    if (!rc && rows) rc = scan ? queue_rows(h, rows) : emit_bytes(h->d_out, (size_t)(rows * h->pl.row_bytes), h->stream);
   }
+  if (!rc && scan) rc = drain_scan(true);
   {   // stop the threads: the reader may be waiting for a slot, the writer for data
     { std::lock_guard<std::mutex> lk(qin.m); qin.stop = true; qin.cv.notify_all(); }
     reader.join();
@@ -1591,10 +1646,15 @@ int run_file_pipelined(frbch_handle* h, int in_fd, int out_fd) {
       qout.cv.notify_all();
     }
     writer.join();
-    if (!rc && qout.error) rc = fail(h, FRBCH_E_IO, std::string("write: ") + strerror(qout.error));
+    if (!rc && qout.error) rc = fail(h0, FRBCH_E_IO, std::string("write: ") + strerror(qout.error));
   }
   release();
   return rc;
+}
+
+int run_file_pipelined(frbch_handle* h, int in_fd, int out_fd) {
+  frbch_handle* hs[1] = {h};
+  return run_pipelined(hs, 1, &in_fd, out_fd, nullptr, 0);
 }
 
 }  // namespace
@@ -1678,7 +1738,7 @@ extern "C" int frbch_run_scan(frbch_handle* const* ifs, uint32_t nif, const char
   CHECK_DEV(h0, dev_set(h0->device), "hipSetDevice");
   const Plan& pl = h0->pl;
   const size_t seg = pl.row_bytes / pl.nif, line_pitch = seg * nif, row_pitch = line_pitch * pl.nif;
-  const uint64_t rows_cap = 2 * (pl.interval_rows + 2ull * pl.maxb * pl.rows_per_block) + 16;
+  const uint64_t rows_cap = pl.interval_rows + 3ull * pl.maxb * pl.rows_per_block + 16;   // one completed interval + batches in flight
   uint8_t* d_rows = nullptr;
   CHECK_DEV(h0, dev_malloc((void**)&d_rows, rows_cap * row_pitch), "hipMalloc(scan rows)");
   std::vector<FILE*> in(nif, nullptr);
@@ -1703,6 +1763,25 @@ extern "C" int frbch_run_scan(frbch_handle* const* ifs, uint32_t nif, const char
   if (!rc) {
     fd = open(out_fil, O_WRONLY | O_CREAT | O_TRUNC, 0644);   // no O_EXCL: may be a FIFO (INSTALL.md:32-35)
     if (fd < 0) rc = fail(h0, FRBCH_E_IO, std::string("cannot open ") + out_fil + ": " + strerror(errno));
+  }
+  if (!rc && !getenv("FRBCH_NO_PIPELINE")) {   // regular input files: overlapped read / transform / write (run_pipelined)
+    std::vector<int> fds(nif, -1);
+    bool regular = true;
+    for (uint32_t i = 0; i < nif; ++i) {
+      fds[i] = open(vdif_paths[i], O_RDONLY);
+      struct stat st;
+      if (fds[i] < 0 || fstat(fds[i], &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 32) regular = false;
+    }
+    if (regular) {
+      rc = run_pipelined(ifs, nif, fds.data(), fd, d_rows, row_pitch);
+      for (int f : fds) if (f >= 0) close(f);
+      const int fd1 = fd;
+      fd = -1;
+      if (fd1 >= 0 && close(fd1) != 0 && !rc) rc = fail(h0, FRBCH_E_IO, std::string("close: ") + strerror(errno));
+      cleanup();
+      return rc;
+    }
+    for (int f : fds) if (f >= 0) close(f);
   }
   if (!rc && dev_host_alloc((void**)&stage, stage_bytes) != 0) rc = fail(h0, FRBCH_E_NOMEM, "pinned staging buffer");
   bool header_done = false;

@@ -299,10 +299,13 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
 
   uint32_t maxb = cfg.max_blocks_per_launch;
   if (!maxb) {
-    // big batches amortise launches and tails and let the persistent kernels run many iterations: up to 8 GiB of spill
-    // (measured, 152-block scan: batches of 64 + 64 + 24 blocks 3.60 ms per step, one batch of 152 or two of 76 3.47 ms)
+    // big batches amortise launches and let the persistent kernels run many iterations: up to 8 GiB of spill, 4 GiB
+    // with four products (the power buffer, the staging areas and a scan's row buffer grow with the batch and with the
+    // products, and the eight handles of a config-3 scan must fit one card: ~15 GB each).  Callers split their blocks
+    // into EQUAL batches (measured, 152-block scan: 64 + 64 + 24 blocks 3.60 ms per step, 3 x 51 3.61 ms, 76 + 76
+    // 3.48 ms, one batch of 152 3.40-3.47 ms).
     const uint64_t spill_per_block = pl->n * 8 * (pl->coherent ? 2 : 1);
-    maxb = (uint32_t)std::max<uint64_t>(1, (8192ull << 20) / spill_per_block);
+    maxb = (uint32_t)std::max<uint64_t>(1, ((cfg.pol_mode == 4 ? 4096ull : 8192ull) << 20) / spill_per_block);
     if (maxb > 256) maxb = 256;
   }
   if (maxb > 32768) maxb = 32768;
