@@ -61,7 +61,11 @@ typedef struct frbch_config {
                                 * 2 generic K2, 4 1024-thread K2, 8 barrier (non wave-private) kernels, 16 4-sequence K2,
                                 * 32 one wave per sequence in K2, 64/128 experimental K1 shapes, 1<<20 rescale statistics in a
                                 * separate pass over the power buffer instead of inside K2; bits 8..19 (flags >> 8)
-                                * are timing-only ablations that produce WRONG output (used by the profiling notes)   */
+                                * are timing-only ablations that produce WRONG output (used by the profiling notes).
+                                * Environment (diagnostics only): FRBCH_NO_K0 (K1 gathers from the frames instead of the
+                                * corner-turned copy), FRBCH_NO_PIPELINE (whole-file paths without reader / writer threads),
+                                * FRBCH_STAMPS=<file> (phase stamps of K1, tools_stamps.py), FRBCH_K1_STAG, FRBCH_GL,
+                                * FRBCH_SPILL_PAD, FRBCH_K2_NPERS, FRBCH_K1_MAXWG (kernel-shape experiments)          */
   char telescope[64];          /* .hdr TELESCOPE  (process_vdif.py:123)                       */
   char source[64];             /* .hdr SOURCE     (:124)                                      */
   char ra[32];                 /* .hdr RA         (:125)                                      */
