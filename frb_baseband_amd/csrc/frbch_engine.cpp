@@ -283,7 +283,7 @@ int k2_wave_nt(const Plan& pl, uint32_t h_flags) {
 // rows of partial sums the fused statistics use; 0 = this configuration cannot fuse (one column group per thread needed)
 int fused_stat_chunks(const Plan& pl, uint32_t h_flags, int pol_mode) {
   if (pol_mode == 3) return 0;   // (PP+QQ)^2: its square overflows the fp32 partial sums (~1e24 squared)
-  if (!pl.fast_k2_log2m || !pl.fast_k2_wave || pl.coherent || (h_flags & (1u << 20))) return 0;
+  if (!(pl.fast_k2_log2m || pl.fast_k2_m1) || !pl.fast_k2_wave || pl.coherent || (h_flags & (1u << 20))) return 0;
   const int nt = k2_wave_nt(pl, h_flags), cg = (int)(pl.ncol / 4);
   if (cg > nt)   // a thread owns cg/nt column groups, one row of sums per workgroup (the MSTAT instantiations: 2C = 2048, two waves per sequence)
     return (cg % nt == 0 && cg / nt <= 4 && pl.fast_k2_log2m == 3 && !(h_flags & 32u) && pl.fast_k2_nw != 8) ? (int)kFusedStatWgs : 0;
@@ -464,6 +464,10 @@ bool launch_k2_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   const Plan& pl = h->pl;
   if (pl.fast_k2_wave) {
     switch (pl.fast_k2_log2m) {
+      case 0:
+        if (!pl.fast_k2_m1) return false;
+        launch_k2_wave_t<0>(pl, p, nb, s, h->cfg.flags);
+        break;
       case 1: launch_k2_wave_t<1>(pl, p, nb, s, h->cfg.flags); break;
       case 2: launch_k2_wave_t<2>(pl, p, nb, s, h->cfg.flags); break;
       case 3: launch_k2_wave_t<3>(pl, p, nb, s, h->cfg.flags); break;
@@ -605,6 +609,16 @@ int setup_fast(frbch_handle* h) {
     }
     if (rc) return rc;
   }
+  if (pl.fast_k2_m1) {   // 2C = 256: wave-private K2 only, Kc stays generic
+    fft_tables(pl.c2, &t1, &t2);
+    if ((rc = upload_cf(h, &h->ftw1_c, t1)) || (rc = upload_cf(h, &h->ftw2_c, t2))) return rc;
+    rc = FRBCH_OK;
+#define FRBCH_ALLOW0(NWV, PMV) if (!rc) rc = allow_lds(h, fast::frbch_k2_wave<0, NWV, PMV>, pl.k2_fast_lds)
+    FRBCH_ALLOW0(2, 0); FRBCH_ALLOW0(2, 2); FRBCH_ALLOW0(2, 4); FRBCH_ALLOW0(4, 0); FRBCH_ALLOW0(4, 2); FRBCH_ALLOW0(4, 4);
+    FRBCH_ALLOW0(8, 0); FRBCH_ALLOW0(8, 2); FRBCH_ALLOW0(8, 4);
+#undef FRBCH_ALLOW0
+    if (rc) return rc;
+  }
   if (pl.fast_k2_log2m) {
     fft_tables(pl.c2, &t1, &t2);
     if ((rc = upload_cf(h, &h->ftw1_c, t1)) || (rc = upload_cf(h, &h->ftw2_c, t2))) return rc;
@@ -719,7 +733,7 @@ int launch_back(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   const int tile_t = std::max(pl.tt, pl.tscr);
   const double out_b = p.out_mode == FRBCH_OUT_FLOAT_POWER ? (double)pl.ncol * 4.0 : (double)pl.row_bytes;
   const double bytes = (double)nb * ((double)pl.n * 8.0 + (double)pl.rows_per_block * out_b);
-  if (!(pl.fast_k2_log2m && pl.fast_k2_wave) || pl.coherent) p.stat_partial = nullptr;   // only the wave-private K2 sums while it writes
+  if (!((pl.fast_k2_log2m || pl.fast_k2_m1) && pl.fast_k2_wave) || pl.coherent) p.stat_partial = nullptr;   // only the wave-private K2 sums while it writes
   if (pl.coherent) {   // K2c (branches -> channels, x kernel), K3 (back to time, detect), K4 (time-major rows)
     {
       ProfScope ps(h, s, KID_K2, (double)nb * (double)pl.n * 24.0);
@@ -999,6 +1013,9 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
       } else {
         snprintf(nm, sizeof nm, "frbch_k2_fast<%d,%d>", pl.fast_k2_log2m, pl.fast_k2_nt);
       }
+      h->kname[KID_K2] = nm;
+    } else if (pl.fast_k2_m1) {
+      snprintf(nm, sizeof nm, "frbch_k2_wave<0,%d,%d,1>", pl.fast_k2_nw, h->cfg.pol_mode == 2 ? 2 : (h->cfg.pol_mode == 4 ? 4 : 0));
       h->kname[KID_K2] = nm;
     }
   }

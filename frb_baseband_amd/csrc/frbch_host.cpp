@@ -196,6 +196,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
   // wave-private variant for M <= 8 (flags & 8 selects the barrier variant instead).
   pl->fast_k1_log2m = pl->fast_k2_log2m = 0;
   pl->fast_k1_wave = pl->fast_k2_wave = 0;
+  pl->fast_k2_m1 = 0;
   pl->fast_k2_nt = (cfg.flags & 4u) ? 1024 : 512;
   pl->k1_fast_lds = pl->k2_fast_lds = 0;
   const bool want_wave = !(cfg.flags & 8u);
@@ -229,7 +230,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
       pl->k1_fast_lds = lds;
     }
   }
-  if (!(cfg.flags & 2u) && pl->c2 >= 512 && pl->c2 <= 8192 && pl->g >= 2 && !pl->coherent) {
+  if (!(cfg.flags & 2u) && pl->c2 >= 256 && pl->c2 <= 8192 && pl->g >= 2 && !pl->coherent) {
     const int m = pl->c2 / 256;
     const bool wave = want_wave && m <= 16 && !(cfg.flags & 4u);
     const int tps = 16 * m;
@@ -254,8 +255,9 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
     const size_t seq = (size_t)pl->c2 + pl->c2 / 8 + (m == 32 ? 0 : 8);
     const size_t lds = (size_t)tt * seq * 8 + (walk ? (size_t)pl->c * 4 : 0);   // + the row of sub-tile sums
     if (tt >= 1 && (pl->tscr <= tt || walk) && tt <= (int)r && (size_t)tt * pl->ncol * 4 <= lds && lds <= lds_limit &&
-        (tt * pl->g) % 2 == 0) {
+        (tt * pl->g) % 2 == 0 && (m > 1 || wave)) {   // 2C = 256 (radix 16 x 16): wave-private kernel only
       pl->fast_k2_log2m = ilog2(m);
+      pl->fast_k2_m1 = m == 1;
       pl->fast_k2_wave = wave ? 1 : 0;
       pl->k2_fast_lds = lds;
     }

@@ -42,7 +42,8 @@ struct Plan {
   size_t k1_lds, k2_lds, kc_lds;
   uint32_t maxb;              // blocks per launch
   int fast_k1_log2m;          // 0 = generic K1, else log2(M) with R = 256*M
-  int fast_k2_log2m;          // 0 = generic K2, else log2(M) with 2C = 256*M
+  int fast_k2_log2m;          // 0 = generic K2 (unless fast_k2_m1), else log2(M) with 2C = 256*M
+  int fast_k2_m1;             // 1 = wave-private K2 for 2C = 256 (M = 1; Kc stays generic)
   int fast_k2_nt;             // threads per K2 workgroup (512 / 1024)
   size_t k1_fast_lds, k2_fast_lds;
   int fast_k1_g;              // branches per wave-private K1 workgroup (<= g)

@@ -10,6 +10,12 @@ CASES = [
     # bw, nchan, secs, kwargs
     (16.0, 128, 0.05, {}),                                   # BASELINE config 1 shape (-F128:512 -d1)
     (-16.0, 128, 0.05, {}),                                  # LSB: no band flip
+    (16.0, 128, 0.05, dict(flags=2)),                        # the same shape with the generic K2 behind the fast K1
+    (16.0, 128, 0.05, dict(pol=4, tscr=8)),                  # 2C = 256 K2 (radix 16 x 16, four sequences per wave), 2 waves per workgroup
+    (-16.0, 128, 0.05, dict(tscr=16, nbit=16)),              # ... 4 waves
+    (16.0, 128, 0.05, dict(pol=4, tscr=32, nbit=-32)),       # ... 8 waves
+    (16.0, 128, 0.05, dict(pol=0, nbit=2, tscr=2)),
+    (16.0, 128, 0.05, dict(pol=3, interval=0.01, const=0)),  # per-interval rescale (pol 3: separate statistics pass)
     (16.0, 64, 0.05, dict(pol=4)),                           # -d4 coherency products
     (-16.0, 32, 0.05, dict(pol=4, nbit=-32, tscr=4, freq_res=64)),
     (16.0, 32, 0.05, dict(pol=0, nbit=2, tscr=2, freq_res=64)),
