@@ -425,6 +425,7 @@ bool launch_k1_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
     set_fastdiv(q);
     if (h->stg_ready) q.stg = h->stg;   // launch_k0_stage has corner-turned this batch
     h->stg_ready = false;
+    q.tile_major = p.tile_major = pl.spill_tile_major;   // (K2 of this batch reads what this launch writes)
     switch (pl.fast_k1_log2m) {
       case 1: launch_k1_wave_t<1>(pl, q, nb, s); break;
       case 2: launch_k1_wave_t<2>(pl, q, nb, s); break;
@@ -704,6 +705,7 @@ int build_chirp(frbch_handle* h, int order_m) {
 // K1 + Kc over nb blocks: frames -> spill, P0
 int launch_front(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   const Plan& pl = h->pl;
+  p.tile_major = 0;   // set by the K1 that writes that layout
   {
     launch_k0_stage(h, p, nb, s);
     const double bytes = (double)nb * ((double)pl.block_payload_bytes * p.frame_bytes / p.payload_bytes +

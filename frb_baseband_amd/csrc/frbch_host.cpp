@@ -197,6 +197,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
   pl->fast_k1_log2m = pl->fast_k2_log2m = 0;
   pl->fast_k1_wave = pl->fast_k2_wave = 0;
   pl->fast_k2_m1 = 0;
+  pl->spill_tile_major = 0;
   pl->fast_k2_nt = (cfg.flags & 4u) ? 1024 : 512;
   pl->k1_fast_lds = pl->k2_fast_lds = 0;
   const bool want_wave = !(cfg.flags & 8u);
@@ -261,6 +262,17 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
       pl->fast_k2_wave = wave ? 1 : 0;
       pl->k2_fast_lds = lds;
     }
+  }
+
+  // tile-major spill: the paired-branch wave K1 (R = 2048, 8 branches per workgroup) in front of a wave K2 whose
+  // workgroup takes two time samples (measured: K2 1.34 -> 1.29 ms, its gather alone 1.06 -> 0.95 ms; K1 unchanged)
+  pl->spill_tile_major = 0;
+  if (pl->fast_k1_wave && pl->fast_k1_log2m == 3 && pl->fast_k1_kind == 0 && pl->fast_k1_g == 8 && pl->g == 8 &&
+      pl->fast_k2_wave && !pl->coherent && !(cfg.flags & (1u << 21))) {   // flag bit 21: keep the slab layout (A/B tests)
+    const int m2 = pl->c2 / 256, tps2 = 16 * m2, spw2 = tps2 < 64 ? 64 / tps2 : 1;
+    const bool two = (m2 == 16) || (m2 == 8 && !(cfg.flags & 32u) && pl->fast_k2_nw != 8);   // two waves per sequence
+    const int tt2 = two ? (pl->fast_k2_nw == 2 ? 2 : 4) : pl->fast_k2_nw * spw2;
+    if (tt2 == 2) pl->spill_tile_major = 1;
   }
 
   // coherent pipeline on the register-pass kernels (barrier variants): K1 forward-only + K3 need R = 256*M, K2c needs

@@ -79,6 +79,8 @@ struct KParams {
   const uint8_t* stg;        // wave K1: the launch's payload re-ordered by frbch_k0_stage, [blk][branch group][row][RB bytes]: the
                              // rows of one workgroup and block are contiguous (null = gather from the frames)
   uint8_t* stg_out;          // frbch_k0_stage: where it writes that buffer
+  int tile_major;            // 1 = this launch's spill is [blk][t/2][n1/G][t%2][n1%G] (paired-branch wave K1 -> wave K2 with
+                             // two time samples per workgroup: a K2 tile is one contiguous run); set per launch by the engine
   unsigned long long* stamps; // diagnostic builds of the wave K1: s_memtime stamps [workgroup][wave][16] of one block; null = off
 };
 

@@ -60,7 +60,8 @@ typedef struct frbch_config {
   uint32_t flags;              /* 0 in production.  Kernel-selection switches for A/B measurements: 1 generic K1,
                                 * 2 generic K2, 4 1024-thread K2, 8 barrier (non wave-private) kernels, 16 4-sequence K2,
                                 * 32 one wave per sequence in K2, 64/128 experimental K1 shapes, 1<<20 rescale statistics in a
-                                * separate pass over the power buffer instead of inside K2; bits 8..19 (flags >> 8)
+                                * separate pass over the power buffer instead of inside K2, 1<<21 slab layout of the spill
+                                * where the tile-major one would be used; bits 8..19 (flags >> 8)
                                 * are timing-only ablations that produce WRONG output (used by the profiling notes).
                                 * Environment (diagnostics only): FRBCH_NO_K0 (K1 gathers from the frames instead of the
                                 * corner-turned copy), FRBCH_NO_PIPELINE (whole-file paths without reader / writer threads),

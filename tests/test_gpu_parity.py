@@ -23,6 +23,8 @@ CASES = [
     (16.0, 32, 0.05, dict(pol=1, freq_res=64, interval=0.004, const=0)),  # no -c: per-interval rescale
     (16.0, 32, 0.05, dict(freq_res=64, interval=0.004, const=1, maxb=3)),
     (32.0, 1024, 0.14, {}),                                  # BASELINE config 2 shape, 2 blocks (fast K1+K2, M=8)
+    (32.0, 1024, 0.14, dict(flags=1 << 21)),                 # slab layout of the spill instead of the tile-major one
+    (-32.0, 1024, 0.14, dict(flags=1 << 21, pol=4, tscr=2)),
     (32.0, 1024, 0.14, dict(flags=3)),                       # same through the generic kernels
     (32.0, 1024, 0.14, dict(flags=1)),                       # generic K1 + fast K2
     (32.0, 1024, 0.14, dict(flags=2)),                       # fast K1 + generic K2
