@@ -425,7 +425,7 @@ bool launch_k1_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
     set_fastdiv(q);
     if (h->stg_ready) q.stg = h->stg;   // launch_k0_stage has corner-turned this batch
     h->stg_ready = false;
-    q.tile_major = p.tile_major = pl.spill_tile_major;   // (K2 of this batch reads what this launch writes)
+    q.tile_major = p.tile_major = pl.spill_tile_major == 2 ? 2 : 0;   // (K2 of this batch reads what this launch writes)
     switch (pl.fast_k1_log2m) {
       case 1: launch_k1_wave_t<1>(pl, q, nb, s); break;
       case 2: launch_k1_wave_t<2>(pl, q, nb, s); break;
@@ -435,6 +435,7 @@ bool launch_k1_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
     }
     return true;
   }
+  p.tile_major = pl.spill_tile_major == 8 ? 8 : 0;   // (K2 of this batch reads what this launch writes)
   KParams q = p;
   if (h->stg_ready) q.stg = h->stg;   // launch_k0_stage has corner-turned this batch
   h->stg_ready = false;
@@ -482,7 +483,10 @@ bool launch_k2_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
     case 2: launch_k2_fast_t<2>(pl, p, nb, s); break;
     case 3: launch_k2_fast_t<3>(pl, p, nb, s); break;
     case 4: launch_k2_fast_t<4>(pl, p, nb, s); break;
-    case 5: hipLaunchKernelGGL((fast::frbch_k2_fast<5, 1024>), dim3(pl.r / std::max(2, pl.tscr), nb), dim3(1024), pl.k2_fast_lds, s, p); break;
+    case 5:
+      if (pl.fast_k2_nt == 512) hipLaunchKernelGGL((fast::frbch_k2_fast<5, 512>), dim3(pl.r, nb), dim3(512), pl.k2_fast_lds, s, p);   // one time sample per workgroup (tscrunch 1)
+      else hipLaunchKernelGGL((fast::frbch_k2_fast<5, 1024>), dim3(pl.r / std::max(2, pl.tscr), nb), dim3(1024), pl.k2_fast_lds, s, p);
+      break;
     default: return false;
   }
   return true;
@@ -666,7 +670,7 @@ int setup_fast(frbch_handle* h) {
       case 2: rc = big ? allow_lds(h, fast::frbch_k2_fast<2, 1024>, pl.k2_fast_lds) : allow_lds(h, fast::frbch_k2_fast<2, 512>, pl.k2_fast_lds); break;
       case 3: rc = big ? allow_lds(h, fast::frbch_k2_fast<3, 1024>, pl.k2_fast_lds) : allow_lds(h, fast::frbch_k2_fast<3, 512>, pl.k2_fast_lds); break;
       case 4: rc = big ? allow_lds(h, fast::frbch_k2_fast<4, 1024>, pl.k2_fast_lds) : allow_lds(h, fast::frbch_k2_fast<4, 512>, pl.k2_fast_lds); break;
-      default: rc = allow_lds(h, fast::frbch_k2_fast<5, 1024>, pl.k2_fast_lds); break;
+      default: rc = big ? allow_lds(h, fast::frbch_k2_fast<5, 1024>, pl.k2_fast_lds) : allow_lds(h, fast::frbch_k2_fast<5, 512>, pl.k2_fast_lds); break;
     }
     if (rc) return rc;
   }

@@ -249,7 +249,9 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
     else if (wave && pl->tscr > 4 * spw)
       nw = 8;
     pl->fast_k2_nw = nw;
-    if (m == 32) pl->fast_k2_nt = 1024;           // 2C = 8192: one workgroup = 2 time samples (147 KB of LDS)
+    // 2C = 8192: one workgroup = 2 time samples (147 KB of LDS, one workgroup per CU), or -- no tscrunch -- ONE time
+    // sample with 512 threads (74 KB: two workgroups per CU, one gathers while the other transforms)
+    if (m == 32) pl->fast_k2_nt = (pl->tscr == 1 && !(cfg.flags & 4u)) ? 512 : 1024;
     const int tt = wave ? nw * spw : pl->fast_k2_nt / tps;
     // 2C = 8192: a workgroup may walk tscrunch/tt tiles and add them up in registers
     const bool walk = m == 32 && pl->nif == 1 && pl->tscr > tt && pl->tscr % tt == 0 && pl->tscr <= (int)r;
@@ -272,8 +274,13 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
     const int m2 = pl->c2 / 256, tps2 = 16 * m2, spw2 = tps2 < 64 ? 64 / tps2 : 1;
     const bool two = (m2 == 16) || (m2 == 8 && !(cfg.flags & 32u) && pl->fast_k2_nw != 8);   // two waves per sequence
     const int tt2 = two ? (pl->fast_k2_nw == 2 ? 2 : 4) : pl->fast_k2_nw * spw2;
-    if (tt2 == 2) pl->spill_tile_major = 1;
+    if (tt2 == 2) pl->spill_tile_major = 2;
   }
+  // chunks of eight time samples between the M = 32 barrier kernels (2 branches per K1 workgroup: the slab layout
+  // leaves K2 one 32-byte piece per 128-KB slab)
+  if (!pl->fast_k1_wave && pl->fast_k1_log2m == 5 && !pl->fast_k2_wave && pl->fast_k2_log2m == 5 && !pl->coherent &&
+      !(cfg.flags & (1u << 21)))
+    pl->spill_tile_major = 8;
 
   // coherent pipeline on the register-pass kernels (barrier variants): K1 forward-only + K3 need R = 256*M, K2c needs
   // 2C = 256*M', M, M' in 2..32; the K1 group (64/M branches) becomes the layout group of the first spill

@@ -79,8 +79,10 @@ struct KParams {
   const uint8_t* stg;        // wave K1: the launch's payload re-ordered by frbch_k0_stage, [blk][branch group][row][RB bytes]: the
                              // rows of one workgroup and block are contiguous (null = gather from the frames)
   uint8_t* stg_out;          // frbch_k0_stage: where it writes that buffer
-  int tile_major;            // 1 = this launch's spill is [blk][t/2][n1/G][t%2][n1%G] (paired-branch wave K1 -> wave K2 with
-                             // two time samples per workgroup: a K2 tile is one contiguous run); set per launch by the engine
+  int tile_major;            // 0 = slab layout.  2 = this launch's spill is [blk][t/2][n1/G][t%2][n1%G] (paired-branch wave K1 -> wave K2
+                             // with two time samples per workgroup: a K2 tile is one contiguous run).  8 = chunks of eight time samples
+                             // [blk][t/8][n1/G][t%8][n1%G] (frbch_k1_fast<5> -> frbch_k2_fast<5>: whole cache lines on both sides).
+                             // Set per launch by the engine (the K1 that runs decides)
   unsigned long long* stamps; // diagnostic builds of the wave K1: s_memtime stamps [workgroup][wave][16] of one block; null = off
 };
 

@@ -73,6 +73,7 @@ CASES = [
     (64.0, 4096, 1.1, dict(tscr=8)),                         # BASELINE config 4 shape (-t 8 -F4096:8192), 2 blocks: M = 32 barrier kernels, K2 walks 4 sub-tiles
     (64.0, 4096, 1.1, dict(tscr=8, flags=3)),                # the same through the generic kernels
     (-64.0, 4096, 1.1, {}),                                  # M = 32, -t 1, LSB
+    (64.0, 4096, 1.1, dict(flags=1 << 21, tscr=2)),          # M = 32 with the slab layout of the spill instead of chunks of eight time samples
     (64.0, 4096, 1.1, dict(pol=4, tscr=2, nbit=16)),         # M = 32, coherency products
     (64.0, 4096, 1.1, dict(pol=4, tscr=4)),                  # four products and tscrunch > 2: generic K2 behind the M = 32 K1
 ]
