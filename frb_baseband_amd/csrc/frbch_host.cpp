@@ -218,7 +218,8 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
     } else if (wave && m == 16) {
       kind = 4;                                   // R = 4096: 8 waves, two per sequence, 4 branches
     }
-    const size_t lds = (size_t)kg * seq * 8 + (size_t)r * (kg / 2) + 128 + (wave ? (size_t)kg * 132 : 0);   // + unpack LUT + coarse delay factors + arrival counters
+    const size_t lds = (size_t)kg * seq * 8 + (size_t)r * (kg / 2) + 128 + (wave ? (size_t)kg * 132 : 0) +   // + unpack LUT + coarse delay factors + arrival counters
+                       (m == 32 ? 4096 : 0);                                                                 // + the radix-32 pass's twiddles (M = 32)
     const size_t generic_lds = (size_t)gfast * seq1;   // fallback for unaligned calls keeps the layout
     static const int gl_env = getenv("FRBCH_GL") ? atoi(getenv("FRBCH_GL")) : 0;   // experiments: layout group = workgroup group
     if (gfast <= pl->c2 && lds <= lds_limit && generic_lds <= lds_limit) {
@@ -256,7 +257,8 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
     // 2C = 8192: a workgroup may walk tscrunch/tt tiles and add them up in registers
     const bool walk = m == 32 && pl->nif == 1 && pl->tscr > tt && pl->tscr % tt == 0 && pl->tscr <= (int)r;
     const size_t seq = (size_t)pl->c2 + pl->c2 / 8 + (m == 32 ? 0 : 8);
-    const size_t lds = (size_t)tt * seq * 8 + (walk ? (size_t)pl->c * 4 : 0);   // + the row of sub-tile sums
+    const size_t lds = (size_t)tt * seq * 8 + (walk ? (size_t)pl->c * 4 : 0) +   // + the row of sub-tile sums
+                       ((m == 32 && pl->fast_k2_nt == 512) ? 4096 : 0);         // + the radix-32 pass's twiddles (single-sample K2)
     if (tt >= 1 && (pl->tscr <= tt || walk) && tt <= (int)r && (size_t)tt * pl->ncol * 4 <= lds && lds <= lds_limit &&
         (tt * pl->g) % 2 == 0 && (m > 1 || wave)) {   // 2C = 256 (radix 16 x 16): wave-private kernel only
       pl->fast_k2_log2m = ilog2(m);
@@ -290,7 +292,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
     const int m = (int)r / 256;
     const int gfast = 64 / m;
     const size_t seq = (size_t)r + r / 8 + 8;
-    const size_t lds1 = (size_t)gfast * seq * 8 + (size_t)r * (gfast / 2 ? gfast / 2 : 1);
+    const size_t lds1 = (size_t)gfast * seq * 8 + (size_t)r * (gfast / 2 ? gfast / 2 : 1) + (m == 32 ? 4096 : 0);
     const size_t seq3 = (size_t)r + r / 8 + (m == 32 ? 0 : 8);
     const int ns = 1024 / (16 * m);                 // sequences per K3 workgroup (pairs of rows)
     const size_t lds3 = (size_t)ns * seq3 * 8;
