@@ -219,7 +219,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
       kind = 4;                                   // R = 4096: 8 waves, two per sequence, 4 branches
     }
     const size_t lds = (size_t)kg * seq * 8 + (size_t)r * (kg / 2) + 128 + (wave ? (size_t)kg * 132 : 0) +   // + unpack LUT + coarse delay factors + arrival counters
-                       (m == 32 ? 4096 : 0);                                                                 // + the radix-32 pass's twiddles (M = 32)
+                       ((m >= 16 && !wave) ? (size_t)m * 128 : 0);                                          // + the radix-M pass's twiddles (barrier kernels, M >= 16)
     const size_t generic_lds = (size_t)gfast * seq1;   // fallback for unaligned calls keeps the layout
     static const int gl_env = getenv("FRBCH_GL") ? atoi(getenv("FRBCH_GL")) : 0;   // experiments: layout group = workgroup group
     if (gfast <= pl->c2 && lds <= lds_limit && generic_lds <= lds_limit) {
@@ -292,10 +292,10 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
     const int m = (int)r / 256;
     const int gfast = 64 / m;
     const size_t seq = (size_t)r + r / 8 + 8;
-    const size_t lds1 = (size_t)gfast * seq * 8 + (size_t)r * (gfast / 2 ? gfast / 2 : 1) + (m == 32 ? 4096 : 0);
+    const size_t lds1 = (size_t)gfast * seq * 8 + (size_t)r * (gfast / 2 ? gfast / 2 : 1) + (m >= 16 ? (size_t)m * 128 : 0);
     const size_t seq3 = (size_t)r + r / 8 + (m == 32 ? 0 : 8);
     const int ns = 1024 / (16 * m);                 // sequences per K3 workgroup (pairs of rows)
-    const size_t lds3 = (size_t)ns * seq3 * 8;
+    const size_t lds3 = (size_t)ns * seq3 * 8 + (m >= 16 ? (size_t)m * 128 : 0);   // + the radix-M pass's twiddles
     if (gfast >= 2 && gfast <= pl->c2 && lds1 <= lds_limit && lds3 <= lds_limit && ns >= 2 && pl->c % (ns / 2) == 0 &&
         (size_t)gfast * seq1 <= lds_limit) {
       pl->coh_fast_r = ilog2(m);
@@ -313,7 +313,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
     const int m = pl->c2 / 256;
     const size_t seq = (size_t)pl->c2 + pl->c2 / 8 + (m == 32 ? 0 : 8);
     const int tt = 1024 / (16 * m);
-    const size_t lds = (size_t)tt * seq * 8;
+    const size_t lds = (size_t)tt * seq * 8 + (m >= 16 ? (size_t)m * 128 : 0);   // + the radix-M pass's twiddles
     if (tt >= 1 && tt <= (int)r && (int)r % tt == 0 && lds <= lds_limit && (tt * pl->g) % 2 == 0 && ((size_t)tt * pl->c2 / 2) % 1024 == 0) {
       pl->coh_fast_c = ilog2(m);
       pl->k2c_fast_lds = lds;
