@@ -509,8 +509,13 @@ bool launch_k2c_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
 bool launch_k3_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   const Plan& pl = h->pl;
   if (!pl.coh_fast_r || !h->coh_order_m) return false;
-  const int np = 1024 / (16 << pl.coh_fast_r) / 2;
+  const int np = pl.coh_nt / (16 << pl.coh_fast_r) / 2;
   const dim3 grid(pl.c / np, nb);
+  if (pl.coh_nt == 512) {
+    if (pl.coh_fast_r != 4) return false;
+    hipLaunchKernelGGL((fast::frbch_k3_fast<4, 512>), grid, dim3(512), pl.k3_fast_lds, s, p);
+    return true;
+  }
   switch (pl.coh_fast_r) {
     case 1: hipLaunchKernelGGL((fast::frbch_k3_fast<1, 1024>), grid, dim3(1024), pl.k3_fast_lds, s, p); break;
     case 2: hipLaunchKernelGGL((fast::frbch_k3_fast<2, 1024>), grid, dim3(1024), pl.k3_fast_lds, s, p); break;
@@ -609,7 +614,7 @@ int setup_fast(frbch_handle* h) {
       case 1: rc = allow_lds(h, fast::frbch_k3_fast<1, 1024>, pl.k3_fast_lds); break;
       case 2: rc = allow_lds(h, fast::frbch_k3_fast<2, 1024>, pl.k3_fast_lds); break;
       case 3: rc = allow_lds(h, fast::frbch_k3_fast<3, 1024>, pl.k3_fast_lds); break;
-      case 4: rc = allow_lds(h, fast::frbch_k3_fast<4, 1024>, pl.k3_fast_lds); break;
+      case 4: rc = pl.coh_nt == 512 ? allow_lds(h, fast::frbch_k3_fast<4, 512>, pl.k3_fast_lds) : allow_lds(h, fast::frbch_k3_fast<4, 1024>, pl.k3_fast_lds); break;
       default: rc = allow_lds(h, fast::frbch_k3_fast<5, 1024>, pl.k3_fast_lds); break;
     }
     if (rc) return rc;

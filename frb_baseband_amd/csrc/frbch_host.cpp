@@ -288,13 +288,16 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
   // 2C = 256*M', M, M' in 2..32; the K1 group (64/M branches) becomes the layout group of the first spill
   pl->coh_fast_r = pl->coh_fast_c = 0;
   pl->k2c_fast_lds = pl->k3_fast_lds = 0;
+  // R = 4096 (M = 16, config 5): 512-thread K3 workgroups (one channel and its mirror), two per CU: one gathers while
+  // the other transforms (K3 2.55 -> 2.20 ms)
+  pl->coh_nt = (pl->coherent && r == 4096 && !(cfg.flags & 4u)) ? 512 : 1024;
   if (pl->coherent && !(cfg.flags & 1u) && r >= 512 && r <= 8192 && in_bits == 2 && pl->c >= 4) {
     const int m = (int)r / 256;
     const int gfast = 64 / m;
     const size_t seq = (size_t)r + r / 8 + 8;
     const size_t lds1 = (size_t)gfast * seq * 8 + (size_t)r * (gfast / 2 ? gfast / 2 : 1) + (m >= 16 ? (size_t)m * 128 : 0);
     const size_t seq3 = (size_t)r + r / 8 + (m == 32 ? 0 : 8);
-    const int ns = 1024 / (16 * m);                 // sequences per K3 workgroup (pairs of rows)
+    const int ns = pl->coh_nt / (16 * m);           // sequences per K3 workgroup (pairs of rows)
     const size_t lds3 = (size_t)ns * seq3 * 8 + (m >= 16 ? (size_t)m * 128 : 0);   // + the radix-M pass's twiddles
     if (gfast >= 2 && gfast <= pl->c2 && lds1 <= lds_limit && lds3 <= lds_limit && ns >= 2 && pl->c % (ns / 2) == 0 &&
         (size_t)gfast * seq1 <= lds_limit) {
@@ -312,7 +315,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
   if (pl->coherent && !(cfg.flags & 2u) && pl->c2 >= 512 && pl->c2 <= 8192 && pl->g >= 2) {
     const int m = pl->c2 / 256;
     const size_t seq = (size_t)pl->c2 + pl->c2 / 8 + (m == 32 ? 0 : 8);
-    const int tt = 1024 / (16 * m);
+    const int tt = 1024 / (16 * m);   // (K2c stays at 1024 threads: with 512 its gather pieces and store runs halve, 2.81 -> 3.6 ms)
     const size_t lds = (size_t)tt * seq * 8 + (m >= 16 ? (size_t)m * 128 : 0);   // + the radix-M pass's twiddles
     if (tt >= 1 && tt <= (int)r && (int)r % tt == 0 && lds <= lds_limit && (tt * pl->g) % 2 == 0 && ((size_t)tt * pl->c2 / 2) % 1024 == 0) {
       pl->coh_fast_c = ilog2(m);

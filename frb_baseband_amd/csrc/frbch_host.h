@@ -45,6 +45,7 @@ struct Plan {
   int fast_k2_log2m;          // 0 = generic K2 (unless fast_k2_m1), else log2(M) with 2C = 256*M
   int spill_tile_major;       // 2 / 8 = the kernel pair in use supports that tile-major spill (KParams::tile_major), 0 = slab layout
   int fast_k2_m1;             // 1 = wave-private K2 for 2C = 256 (M = 1; Kc stays generic)
+  int coh_nt;                 // threads per K3 workgroup: 1024, or 512 at R = 4096 (74 KB of LDS: two workgroups per CU)
   int fast_k2_nt;             // threads per K2 workgroup (512 / 1024)
   size_t k1_fast_lds, k2_fast_lds;
   int fast_k1_g;              // branches per wave-private K1 workgroup (<= g)
