@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfrbch.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK, E_ARG, E_IO, E_FORMAT, E_DEVICE, E_NOMEM, E_STATE, E_CAPACITY = 0, -1, -2, -3, -4, -5, -6, -7
 
@@ -29,6 +29,7 @@ class FrbchConfig(C.Structure):
         ("telescope", C.c_char * 64), ("source", C.c_char * 64),
         ("ra", C.c_char * 32), ("dec", C.c_char * 32), ("datafile", C.c_char * 512),
         ("input_bits", C.c_uint32), ("reserved1", C.c_uint32),
+        ("levels", C.c_float * 4),
     ]
 
 
@@ -46,6 +47,7 @@ class FrbchInfo(C.Structure):
         ("have_rescale", C.c_uint32), ("reserved", C.c_uint32),
         ("frames_seen", C.c_uint64), ("frames_invalid", C.c_uint64), ("frame_gaps", C.c_uint64),
         ("block_stride_bytes", C.c_uint64), ("nfilt_pos", C.c_uint32), ("nfilt_neg", C.c_uint32),
+        ("frames_filled", C.c_uint64),
     ]
 
 
@@ -83,6 +85,8 @@ SYMBOLS = {
     "frbch_flush_device": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_uint64), _P]),
     "frbch_power_device": (C.c_int, [_P, _P, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint64,
                                      C.c_uint64, _P, C.c_size_t, _P]),
+    "frbch_unpack_device": (C.c_int, [_P, _P, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int,
+                                      _P, C.c_size_t, _P]),
     "frbch_get_rescale": (C.c_int, [_P, _P, _P]),
     "frbch_set_rescale": (C.c_int, [_P, _P, _P]),
     "frbch_set_profiling": (C.c_int, [_P, C.c_int]),

@@ -8,15 +8,19 @@ import numpy as np
 from . import _lib
 
 
-class InputError(Exception):
-    """Bad input / unsupported configuration (same class name as process_vdif.py:232-241)."""
+class Error(Exception):
+    """Base class of this module's exceptions (process_vdif.py:227-229): ``except process_vdif.Error`` catches both."""
+
+
+class InputError(Error):
+    """Bad input / unsupported configuration (same class name and base as process_vdif.py:232-241)."""
 
     def __init__(self, message):
         super().__init__(message)
         self.message = message
 
 
-class RunError(Exception):
+class RunError(Error):
     """The channeliser failed while running (process_vdif.py:244-253)."""
 
     def __init__(self, message):
@@ -33,6 +37,8 @@ def new_config(lib=None, **kw) -> _lib.FrbchConfig:
             raise InputError(f"unknown configuration field {key!r}")
         if isinstance(val, str):
             val = val.encode()
+        if key == "levels":
+            val = (C.c_float * 4)(*[float(x) for x in val])
         setattr(cfg, key, val)
     return cfg
 
@@ -144,6 +150,11 @@ class Channeliser:
                      payload_off: int, nblocks: int, d_power_ptr: int, cap: int, stream: int = 0) -> None:
         self._check(self.lib.frbch_power_device(self._h, d_frames_ptr, nframes, frame_bytes, header_bytes,
                                                 payload_off, nblocks, d_power_ptr, cap, stream or None))
+
+    def unpack_device(self, d_frames_ptr: int, nframes: int, frame_bytes: int, header_bytes: int, payload_off: int,
+                      nsamples: int, decoder: int, d_volt_ptr: int, cap: int, stream: int = 0) -> None:
+        self._check(self.lib.frbch_unpack_device(self._h, d_frames_ptr, nframes, frame_bytes, header_bytes, payload_off,
+                                                 nsamples, decoder, d_volt_ptr, cap, stream or None))
 
     # -- rescale state ---------------------------------------------------------------------------
     def get_rescale(self):

@@ -35,6 +35,10 @@ static inline int dev_count() {
   return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 static inline int dev_set(int d) { return hipSetDevice(d) == hipSuccess ? 0 : -1; }
+static inline int dev_get() {
+  int d = -1;
+  return hipGetDevice(&d) == hipSuccess ? d : -1;
+}
 static inline int dev_arch_ok(int d, char* name, size_t cap, size_t* lds_limit) {
   hipDeviceProp_t pr;
   if (hipGetDeviceProperties(&pr, d) != hipSuccess) return 0;

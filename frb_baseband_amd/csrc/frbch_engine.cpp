@@ -52,6 +52,7 @@ struct frbch_handle {
   std::string err;
   int device = 0;
   dev_stream_t stream = 0;
+  dev_stream_t user_stream = 0;   // last caller stream the device entry points launched on (0 = none pending)
   size_t lds_limit = 65536;
 
   // constant tables
@@ -116,6 +117,29 @@ int fail(frbch_handle* h, int code, const std::string& msg) {
   h->err = msg;
   return code;
 }
+
+// Every entry point that touches HIP runs with the handle's device current and restores the caller's device on the
+// way out: handles may be driven from any thread, next to other handles or to torch on other GPUs.
+struct DeviceGuard {
+  int prev, want;
+  explicit DeviceGuard(int dev) : prev(dev_get()), want(dev) {
+    if (prev != want) (void)dev_set(want);
+  }
+  ~DeviceGuard() {
+    if (prev >= 0 && prev != want) (void)dev_set(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+// kernel-selection switches a product build accepts (include/frbch.h); everything else is an experiment
+constexpr uint32_t kProductFlags = 1u | 2u | 4u | 8u | 16u | 32u | 64u | 128u | (1u << 20) | (1u << 21) | (1u << 22) | (1u << 23) | (1u << 24);
+constexpr uint32_t kFlagNoPipeline = 1u << 22, kFlagNoK0 = 1u << 23;
+#ifdef FRBCH_EXPERIMENTS
+constexpr uint32_t kAcceptedFlags = kProductFlags | 0x000FFF00u;
+#else
+constexpr uint32_t kAcceptedFlags = kProductFlags;
+#endif
 
 #define CHECK_DEV(h, expr, what)                                                           \
   do {                                                                                     \
@@ -200,14 +224,20 @@ KParams base_params(const frbch_handle* h) {
   p.td2 = h->td2;
   p.offset = h->offset;
   p.scale = h->scale;
-  p.lut[0] = -3.3359f;
-  p.lut[1] = -1.0f;
-  p.lut[2] = 1.0f;
-  p.lut[3] = 3.3359f;
+  {   // 2-bit level table: DSPSR's static one unless the configuration brings its own
+    const float* lv = h->cfg.levels;
+    const bool own = lv[0] != 0.f || lv[1] != 0.f || lv[2] != 0.f || lv[3] != 0.f;
+    static const float dflt[4] = {-3.3359f, -1.0f, 1.0f, 3.3359f};
+    for (int i = 0; i < 4; ++i) p.lut[i] = own ? lv[i] : dflt[i];
+  }
   p.digi_mean = pl.digi_mean;
   p.digi_scale = pl.digi_scale;
   p.digi_max = pl.digi_max;
-  p.dbg = (h->cfg.flags >> 8) & 0xFFFu;   // bits 8..19; bit 20 selects the separate statistics pass
+#ifdef FRBCH_EXPERIMENTS
+  p.dbg = (h->cfg.flags >> 8) & 0xFFFu;   // bits 8..19: timing-only ablations (wrong output)
+#else
+  p.dbg = 0;
+#endif
   p.coherent = pl.coherent;
   p.nfilt_pos = pl.nfilt_pos;
   p.keep = pl.keep;
@@ -227,8 +257,12 @@ template <int LOG2M>
 void launch_k1_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
   // persistent over blocks: the resident workgroups each keep their branch group and loop over the batch
   p.nblk = nb;
+#ifdef FRBCH_EXPERIMENTS
   static const int stag_env = getenv("FRBCH_K1_STAG") ? atoi(getenv("FRBCH_K1_STAG")) : 3;   // priority schedule (3: the halves swap priority behind the forward passes; measured 1.96 -> 1.94 ms)
   p.stag = stag_env;
+#else
+  p.stag = 3;
+#endif
   const int kg = pl.fast_k1_g;            // branches per workgroup (<= pl.g, the layout group)
   {
     static const int ks[6] = {1, 2, 3, 4, 8, 12};
@@ -240,7 +274,11 @@ void launch_k1_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
     }
   }
   const uint32_t ngrp = (uint32_t)(pl.c2 / kg);
+#ifdef FRBCH_EXPERIMENTS
   static const char* stamp_path = getenv("FRBCH_STAMPS");   // diagnostic: phase stamps of one block, dumped after every launch
+#else
+  const char* const stamp_path = nullptr;
+#endif
   static unsigned long long* stamp_buf = nullptr;
   const size_t stamp_n = (size_t)ngrp * 16 * 16;
   if (stamp_path) {
@@ -248,7 +286,11 @@ void launch_k1_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
     (void)hipMemsetAsync(stamp_buf, 0, stamp_n * 8, s);
     p.stamps = stamp_buf;
   }
-  static const uint32_t cap_env = getenv("FRBCH_K1_MAXWG") ? (uint32_t)atoi(getenv("FRBCH_K1_MAXWG")) : 0u;   // experiments
+#ifdef FRBCH_EXPERIMENTS
+  static const uint32_t cap_env = getenv("FRBCH_K1_MAXWG") ? (uint32_t)atoi(getenv("FRBCH_K1_MAXWG")) : 0u;
+#else
+  const uint32_t cap_env = 0u;
+#endif
   const uint32_t resident = cap_env ? cap_env : 256u * (uint32_t)std::max<size_t>(1, (160 * 1024) / pl.k1_fast_lds);
   uint32_t ny = std::max<uint32_t>(1, std::min<uint32_t>(nb, resident / std::max<uint32_t>(1, ngrp)));
 #define FRBCH_K1W(L, NWV, WPSV, NTV)                                                                                       \
@@ -297,11 +339,15 @@ void launch_k2_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s, u
   // persistent: one wave of workgroups loops over the (tiles per block) x nb tiles of the launch
   p.nblk = nb;
   if (!fused_stat_chunks(pl, h_flags, p.pol_mode)) p.stat_partial = nullptr;
-  static const uint32_t npers_env = getenv("FRBCH_K2_NPERS") ? (uint32_t)atoi(getenv("FRBCH_K2_NPERS")) : 0u;   // experiments
+#ifdef FRBCH_EXPERIMENTS
+  static const uint32_t npers_env = getenv("FRBCH_K2_NPERS") ? (uint32_t)atoi(getenv("FRBCH_K2_NPERS")) : 0u;
+#else
+  const uint32_t npers_env = 0u;
+#endif
   const uint32_t npers = p.stat_partial ? kFusedStatWgs : (npers_env ? npers_env : 8192u);   // measured: 768 (= resident) 1.59 ms, 2048 1.56, 8192 1.49 (shorter tail)
   auto pers = [&](uint32_t tiles_per_block) { return dim3(std::min<uint64_t>((uint64_t)tiles_per_block * nb, npers)); };
   const dim3 grid2 = pers(pl.r / (2 * spw)), grid4 = pers(pl.r / (4 * spw)), grid8 = pers(pl.r / (8 * spw));
-  const int pm = p.pol_mode == 2 ? 2 : (p.pol_mode == 4 ? 4 : 0);
+  const int pm = p.pol_mode == 2 ? 2 : (p.pol_mode >= 4 ? 4 : 0);
 #define FRBCH_K2W(NWV, PMV, GRID) hipLaunchKernelGGL((fast::frbch_k2_wave<LOG2M, NWV, PMV>), GRID, dim3(64 * NWV), pl.k2_fast_lds, s, p)
   if constexpr (LOG2M == 4) {   // 2C = 4096: two waves per sequence; 2 or 4 sequences per workgroup
     if (pl.fast_k2_nw == 2) {
@@ -376,7 +422,7 @@ bool launch_kc_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
 void launch_k0_stage(frbch_handle* h, const KParams& p, uint32_t nb, dev_stream_t s) {
   const Plan& pl = h->pl;
   h->stg_ready = false;
-  static const bool no_k0 = getenv("FRBCH_NO_K0") != nullptr;   // experiments: gather straight from the frames
+  const bool no_k0 = (h->cfg.flags & kFlagNoK0) != 0;   // gather straight from the frames
   if (!h->stg || no_k0 || !pl.fast_k1_log2m || pl.c % 256 != 0 || pl.r % 64 != 0) return;
   if (pl.coherent && !h->coh_order_m) return;              // the generic K1 is in use
   const uint32_t rb = (uint32_t)(pl.fast_k1_wave ? pl.fast_k1_g : pl.g) / 2;
@@ -971,7 +1017,11 @@ int set_identity_rescale(frbch_handle* h) {
 // =============================================================================================
 // C ABI
 // =============================================================================================
-extern "C" const char* frbch_version(void) { return "frbch abi 1 backend " FRBCH_BACKEND_NAME; }
+#ifdef FRBCH_EXPERIMENTS
+extern "C" const char* frbch_version(void) { return "frbch abi 2 backend " FRBCH_BACKEND_NAME " +experiments"; }
+#else
+extern "C" const char* frbch_version(void) { return "frbch abi 2 backend " FRBCH_BACKEND_NAME; }
+#endif
 
 extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
   if (!cfg || !out) return FRBCH_E_ARG;
@@ -984,8 +1034,10 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
   const int ndev = dev_count();
   if (ndev <= 0) return fail(h, FRBCH_E_DEVICE, "no GPU visible to HIP (there is no CPU fallback)");
   if (cfg->device >= ndev) return fail(h, FRBCH_E_DEVICE, "device ordinal out of range");
+  if (cfg->flags & ~kAcceptedFlags)
+    return fail(h, FRBCH_E_ARG, "unknown bit in cfg.flags (timing-only ablations exist only in FRBCH_EXPERIMENTS builds)");
   h->device = cfg->device;
-  CHECK_DEV(h, dev_set(h->device), "hipSetDevice");
+  DeviceGuard dg(h->device);
   char arch[128] = "";
   if (!dev_arch_ok(h->device, arch, sizeof arch, &h->lds_limit)) return fail(h, FRBCH_E_DEVICE, "cannot query device");
   const std::string why = make_plan(h->cfg, &h->pl, h->lds_limit);
@@ -1019,14 +1071,14 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
       if (pl.fast_k2_wave) {
         const bool two = (pl.fast_k2_log2m == 4) || (pl.fast_k2_log2m == 3 && !(h->cfg.flags & 32u) && pl.fast_k2_nw != 8);
         const int nw = two ? (pl.fast_k2_nw == 2 ? 4 : 8) : pl.fast_k2_nw;
-        const int pm = h->cfg.pol_mode == 2 ? 2 : (h->cfg.pol_mode == 4 ? 4 : 0);
+        const int pm = h->cfg.pol_mode == 2 ? 2 : (h->cfg.pol_mode >= 4 ? 4 : 0);
         snprintf(nm, sizeof nm, "frbch_k2_wave<%d,%d,%d,%d>", pl.fast_k2_log2m, nw, pm, two ? 2 : 1);
       } else {
         snprintf(nm, sizeof nm, "frbch_k2_fast<%d,%d>", pl.fast_k2_log2m, pl.fast_k2_nt);
       }
       h->kname[KID_K2] = nm;
     } else if (pl.fast_k2_m1) {
-      snprintf(nm, sizeof nm, "frbch_k2_wave<0,%d,%d,1>", pl.fast_k2_nw, h->cfg.pol_mode == 2 ? 2 : (h->cfg.pol_mode == 4 ? 4 : 0));
+      snprintf(nm, sizeof nm, "frbch_k2_wave<0,%d,%d,1>", pl.fast_k2_nw, h->cfg.pol_mode == 2 ? 2 : (h->cfg.pol_mode >= 4 ? 4 : 0));
       h->kname[KID_K2] = nm;
     }
   }
@@ -1056,6 +1108,8 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
 
 extern "C" void frbch_close(frbch_handle* h) {
   if (!h) return;
+  DeviceGuard dg(h->device);
+  if (h->user_stream) (void)dev_sync(h->user_stream);
   if (h->stream) (void)dev_sync(h->stream);
   drain_events(h);
   dev_free(h->tw_r); dev_free(h->tw_c2); dev_free(h->tw_nhi); dev_free(h->tw_nlo);
@@ -1098,8 +1152,20 @@ extern "C" int frbch_get_info(frbch_handle* h, frbch_info* info) {
   return FRBCH_OK;
 }
 
+// Work the device entry points queued on a caller's stream (statistics writing offset / scale, the digitiser reading
+// them, the power buffer) must be complete before the handle's own stream or the host touches that state.
+static int settle_user_stream(frbch_handle* h) {
+  if (h->user_stream) {
+    CHECK_DEV(h, dev_sync(h->user_stream), "sync (caller stream)");
+    h->user_stream = 0;
+  }
+  return FRBCH_OK;
+}
+
 extern "C" int frbch_reset(frbch_handle* h) {
   if (!h) return FRBCH_E_ARG;
+  DeviceGuard dg(h->device);
+  { const int rc = settle_user_stream(h); if (rc) return rc; }
   CHECK_DEV(h, dev_sync(h->stream), "sync");
   h->pow_rows = 0;
   h->fused_rows = 0;
@@ -1124,6 +1190,8 @@ extern "C" int frbch_reset(frbch_handle* h) {
 extern "C" int frbch_get_rescale(frbch_handle* h, float* offset, float* scale) {
   if (!h || !offset || !scale) return FRBCH_E_ARG;
   if (!h->have_scale) return fail(h, FRBCH_E_STATE, "rescale not measured yet");
+  DeviceGuard dg(h->device);
+  { const int rc = settle_user_stream(h); if (rc) return rc; }
   CHECK_DEV(h, dev_d2h(offset, h->offset, h->pl.ncol * sizeof(float), h->stream), "download offset");
   CHECK_DEV(h, dev_d2h(scale, h->scale, h->pl.ncol * sizeof(float), h->stream), "download scale");
   CHECK_DEV(h, dev_sync(h->stream), "sync");
@@ -1133,6 +1201,8 @@ extern "C" int frbch_get_rescale(frbch_handle* h, float* offset, float* scale) {
 extern "C" int frbch_set_rescale(frbch_handle* h, const float* offset, const float* scale) {
   if (!h || !offset || !scale) return FRBCH_E_ARG;
   if (h->pow_rows) return fail(h, FRBCH_E_STATE, "set_rescale while an interval is being measured");
+  DeviceGuard dg(h->device);
+  { const int rc = settle_user_stream(h); if (rc) return rc; }
   CHECK_DEV(h, dev_h2d(h->offset, offset, h->pl.ncol * sizeof(float), h->stream), "upload offset");
   CHECK_DEV(h, dev_h2d(h->scale, scale, h->pl.ncol * sizeof(float), h->stream), "upload scale");
   CHECK_DEV(h, dev_sync(h->stream), "sync");
@@ -1149,7 +1219,12 @@ extern "C" int frbch_process_device(frbch_handle* h, const void* d_frames, size_
   if (nblocks && payload_byte_offset + (nblocks - 1) * h->pl.block_stride_bytes + h->pl.block_payload_bytes > payload)
     return fail(h, FRBCH_E_ARG, "frames do not cover the requested blocks");
   if (nblocks && !d_out) return FRBCH_E_ARG;
+  DeviceGuard dg(h->device);
   dev_stream_t s = stream ? (dev_stream_t)stream : h->stream;
+  if (stream) {
+    if (h->user_stream && h->user_stream != s) { const int rc = settle_user_stream(h); if (rc) return rc; }
+    h->user_stream = s;
+  }
   return engine_feed(h, (const uint8_t*)d_frames, frame_bytes, header_bytes, payload_byte_offset, nblocks,
                      (uint8_t*)d_out, out_cap_bytes, rows_written, s);
 }
@@ -1157,7 +1232,12 @@ extern "C" int frbch_process_device(frbch_handle* h, const void* d_frames, size_
 extern "C" int frbch_flush_device(frbch_handle* h, void* d_out, size_t out_cap_bytes, uint64_t* rows_written,
                                   void* stream) {
   if (!h || !rows_written) return FRBCH_E_ARG;
+  DeviceGuard dg(h->device);
   dev_stream_t s = stream ? (dev_stream_t)stream : h->stream;
+  if (stream) {
+    if (h->user_stream && h->user_stream != s) { const int rc = settle_user_stream(h); if (rc) return rc; }
+    h->user_stream = s;
+  }
   return engine_flush(h, (uint8_t*)d_out, out_cap_bytes, rows_written, s);
 }
 
@@ -1171,7 +1251,12 @@ extern "C" int frbch_power_device(frbch_handle* h, const void* d_frames, size_t 
     return fail(h, FRBCH_E_ARG, "frames do not cover the requested blocks");
   if (nblocks * pl.rows_per_block * pl.ncol * sizeof(float) > cap_bytes)
     return fail(h, FRBCH_E_CAPACITY, "power buffer too small");
+  DeviceGuard dg(h->device);
   dev_stream_t s = stream ? (dev_stream_t)stream : h->stream;
+  if (stream) {
+    if (h->user_stream && h->user_stream != s) { const int rc = settle_user_stream(h); if (rc) return rc; }
+    h->user_stream = s;
+  }
   for (uint64_t b0 = 0; b0 < nblocks; b0 += pl.maxb) {
     const uint32_t nb = (uint32_t)std::min<uint64_t>(pl.maxb, nblocks - b0);
     KParams p = base_params(h);
@@ -1191,6 +1276,47 @@ extern "C" int frbch_power_device(frbch_handle* h, const void* d_frames, size_t 
   return FRBCH_OK;
 }
 
+// the unpack tap: voltages as the filterbank sees them (A4 in isolation)
+extern "C" int frbch_unpack_device(frbch_handle* h, const void* d_frames, size_t nframes, uint32_t frame_bytes,
+                                   uint32_t header_bytes, uint64_t payload_byte_offset, uint64_t nsamples, int decoder,
+                                   float* d_volt, size_t cap_bytes, void* stream) {
+  if (!h || !d_frames || !d_volt || frame_bytes <= header_bytes) return FRBCH_E_ARG;
+  const Plan& pl = h->pl;
+  const uint64_t spb = 4 / (uint64_t)pl.in_bits;
+  const uint64_t payload = (uint64_t)nframes * (frame_bytes - header_bytes);
+  if (payload_byte_offset + (nsamples + spb - 1) / spb > payload) return fail(h, FRBCH_E_ARG, "frames do not cover the requested samples");
+  if (decoder != 0 && decoder != 1) return fail(h, FRBCH_E_ARG, "decoder must be 0 (generic K1) or 1 (register kernels)");
+  if (decoder == 1 && (pl.in_bits != 2 || (nsamples & 1))) return fail(h, FRBCH_E_ARG, "the register kernels decode 2-bit input, two samples per byte");
+  const uint64_t need = (decoder ? 4 : 2) * nsamples * sizeof(float);
+  if (need > cap_bytes) return fail(h, FRBCH_E_CAPACITY, "voltage buffer too small");
+  if (!nsamples) return FRBCH_OK;
+  DeviceGuard dg(h->device);
+  dev_stream_t s = stream ? (dev_stream_t)stream : h->stream;
+  if (stream) {
+    if (h->user_stream && h->user_stream != s) { const int rc = settle_user_stream(h); if (rc) return rc; }
+    h->user_stream = s;
+  }
+  KParams p = base_params(h);
+  p.frames = (const uint8_t*)d_frames;
+  p.frame_bytes = frame_bytes;
+  p.header_bytes = header_bytes;
+  p.payload_bytes = frame_bytes - header_bytes;
+  p.payload_off = payload_byte_offset;
+  p.power_out = d_volt;
+  p.row0 = nsamples;
+  if (decoder == 0) {
+    DEV_LAUNCH(frbch_unpack_tap, (nsamples + 255) / 256, 1, 256, 0, s, p);
+  } else {
+#ifndef FRBCH_NO_FAST
+    hipLaunchKernelGGL(fast::frbch_unpack_tap_fast, dim3((unsigned)((nsamples / 2 + 255) / 256)), dim3(256), 0, s, p);
+#else
+    return fail(h, FRBCH_E_ARG, "the register kernels are not part of this build");
+#endif
+  }
+  CHECK_DEV(h, dev_check_launch(), "launch unpack tap");
+  return FRBCH_OK;
+}
+
 // ---- profiling ---------------------------------------------------------------------------------
 extern "C" int frbch_set_profiling(frbch_handle* h, int enable) {
   if (!h) return FRBCH_E_ARG;
@@ -1199,6 +1325,8 @@ extern "C" int frbch_set_profiling(frbch_handle* h, int enable) {
 }
 extern "C" int frbch_timing_reset(frbch_handle* h) {
   if (!h) return FRBCH_E_ARG;
+  DeviceGuard dg(h->device);
+  if (h->user_stream) (void)dev_sync(h->user_stream);
   (void)dev_sync(h->stream);
   drain_events(h);
   for (int i = 0; i < KID_COUNT; ++i) h->acc_ms[i] = h->acc_bytes[i] = 0.0, h->acc_launches[i] = 0;
@@ -1206,6 +1334,7 @@ extern "C" int frbch_timing_reset(frbch_handle* h) {
 }
 extern "C" int frbch_get_timing(frbch_handle* h, frbch_timing* t) {
   if (!h || !t) return FRBCH_E_ARG;
+  DeviceGuard dg(h->device);
   drain_events(h);
   memset(t, 0, sizeof *t);
   t->size = (uint32_t)sizeof *t;
@@ -1358,6 +1487,7 @@ int process_carry(frbch_handle* h) {
 extern "C" int frbch_push(frbch_handle* h, const uint8_t* frames, size_t nbytes) {
   if (!h || (!frames && nbytes)) return FRBCH_E_ARG;
   if (h->have_vdif && h->blocks_budget == 0) return FRBCH_OK;
+  DeviceGuard dg(h->device);
   h->carry.insert(h->carry.end(), frames, frames + nbytes);
   if (!h->have_vdif) {
     if (h->carry.size() < 32) return FRBCH_OK;
@@ -1370,6 +1500,7 @@ extern "C" int frbch_push(frbch_handle* h, const uint8_t* frames, size_t nbytes)
 extern "C" int frbch_flush(frbch_handle* h) {
   if (!h) return FRBCH_E_ARG;
   if (!h->have_vdif) return FRBCH_OK;
+  DeviceGuard dg(h->device);
   uint64_t rows = 0;
   int rc = engine_flush(h, h->d_out, h->d_out_cap, &rows, h->stream);
   if (rc) return rc;
@@ -1689,7 +1820,8 @@ int run_file_pipelined(frbch_handle* h, int in_fd, int out_fd) {
 
 extern "C" int frbch_run_file(frbch_handle* h, const char* vdif_path, const char* out_fil) {
   if (!h || !vdif_path || !out_fil) return FRBCH_E_ARG;
-  if (!getenv("FRBCH_NO_PIPELINE")) {   // regular input file: overlapped read / transform / write
+  DeviceGuard dg(h->device);
+  if (!(h->cfg.flags & kFlagNoPipeline)) {   // regular input file: overlapped read / transform / write
     const int in_fd = open(vdif_path, O_RDONLY);
     if (in_fd < 0) return fail(h, FRBCH_E_IO, std::string("cannot open ") + vdif_path + ": " + strerror(errno));
     struct stat st;
@@ -1752,6 +1884,7 @@ extern "C" int frbch_run_file(frbch_handle* h, const char* vdif_path, const char
 // =============================================================================================
 // One scan, several IFs on one GPU: replaces N digifil processes + N FIFOs + splice
 // =============================================================================================
+static constexpr size_t kScanPushBytes = 32u << 20;   // bytes of one IF pushed between two drains of the fallback loop
 extern "C" int frbch_run_scan(frbch_handle* const* ifs, uint32_t nif, const char* const* vdif_paths, const char* out_fil) {
   if (!ifs || !nif || !vdif_paths || !out_fil || !ifs[0]) return FRBCH_E_ARG;
   frbch_handle* h0 = ifs[0];
@@ -1763,10 +1896,18 @@ extern "C" int frbch_run_scan(frbch_handle* const* ifs, uint32_t nif, const char
       return fail(h0, FRBCH_E_ARG, "the IFs of a scan must share device, nchan, tscrunch, nbit and products");
     if (ifs[i]->have_vdif) return fail(h0, FRBCH_E_STATE, "frbch_run_scan needs freshly opened (or reset) handles");
   }
-  CHECK_DEV(h0, dev_set(h0->device), "hipSetDevice");
+  DeviceGuard dg(h0->device);
   const Plan& pl = h0->pl;
   const size_t seg = pl.row_bytes / pl.nif, line_pitch = seg * nif, row_pitch = line_pitch * pl.nif;
-  const uint64_t rows_cap = pl.interval_rows + 3ull * pl.maxb * pl.rows_per_block + 16;   // one completed interval + batches in flight
+  // one completed interval + the batches one round can deliver: the pipelined path drains after every batch round (3
+  // batches of slack); the push-driven fallback pushes kScanPushBytes per IF between drains, which small blocks turn
+  // into several batches
+  uint64_t push_batches = 0;
+  for (uint32_t i = 0; i < nif; ++i) {
+    const Plan& q = ifs[i]->pl;
+    push_batches = std::max<uint64_t>(push_batches, kScanPushBytes / std::max<uint64_t>(1, (uint64_t)q.maxb * q.block_stride_bytes) + 2);
+  }
+  const uint64_t rows_cap = pl.interval_rows + std::max<uint64_t>(3, push_batches) * pl.maxb * pl.rows_per_block + 16;
   uint8_t* d_rows = nullptr;
   CHECK_DEV(h0, dev_malloc((void**)&d_rows, rows_cap * row_pitch), "hipMalloc(scan rows)");
   std::vector<FILE*> in(nif, nullptr);
@@ -1792,7 +1933,7 @@ extern "C" int frbch_run_scan(frbch_handle* const* ifs, uint32_t nif, const char
     fd = open(out_fil, O_WRONLY | O_CREAT | O_TRUNC, 0644);   // no O_EXCL: may be a FIFO (INSTALL.md:32-35)
     if (fd < 0) rc = fail(h0, FRBCH_E_IO, std::string("cannot open ") + out_fil + ": " + strerror(errno));
   }
-  if (!rc && !getenv("FRBCH_NO_PIPELINE")) {   // regular input files: overlapped read / transform / write (run_pipelined)
+  if (!rc && !(h0->cfg.flags & kFlagNoPipeline)) {   // regular input files: overlapped read / transform / write (run_pipelined)
     std::vector<int> fds(nif, -1);
     bool regular = true;
     for (uint32_t i = 0; i < nif; ++i) {
@@ -1852,7 +1993,7 @@ extern "C" int frbch_run_scan(frbch_handle* const* ifs, uint32_t nif, const char
     (void)most;
     return FRBCH_OK;
   };
-  std::vector<uint8_t> buf(32u << 20);
+  std::vector<uint8_t> buf(kScanPushBytes);
   std::vector<bool> eof(nif, false);
   while (!rc) {
     bool any = false;

@@ -112,8 +112,8 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
   if (r < 2 || !is_pow2(r) || r > 16384) return "freq_res must be a power of two in [2, 16384]";
   const uint32_t t = cfg.tscrunch ? cfg.tscrunch : 1;
   if (!is_pow2(t) || t > r) return "tscrunch must be a power of two not larger than freq_res";
-  if (cfg.pol_mode < 0 || cfg.pol_mode > 4) {
-    e << "pol = " << cfg.pol_mode << " not implemented. Choices are 0, 1, 2, 3, 4";
+  if (cfg.pol_mode < 0 || cfg.pol_mode > 5) {
+    e << "pol = " << cfg.pol_mode << " not implemented. Choices are 0, 1, 2, 3, 4 (and 5 = IQUV)";
     return e.str();
   }
   if (cfg.nbit_out != 2 && cfg.nbit_out != 8 && cfg.nbit_out != 16 && cfg.nbit_out != -32) {
@@ -139,7 +139,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
   pl->log2_n = pl->log2_c2 + pl->log2_r;
   pl->log2_nlo = (pl->log2_n + 1) / 2;
   pl->tscr = (int)t;
-  pl->nif = cfg.pol_mode == 4 ? 4 : 1;
+  pl->nif = cfg.pol_mode >= 4 ? 4 : 1;   // 4: coherency products, 5: Stokes I,Q,U,V
   pl->flip = cfg.bw_mhz > 0 ? 1 : 0;
   pl->nthreads = 256;
   pl->ncol = (uint64_t)pl->nif * pl->c;
@@ -221,7 +221,11 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
     const size_t lds = (size_t)kg * seq * 8 + (size_t)r * (kg / 2) + 128 + (wave ? (size_t)kg * 132 : 0) +   // + unpack LUT + coarse delay factors + arrival counters
                        ((m >= 16 && !wave) ? (size_t)m * 128 : 0);                                          // + the radix-M pass's twiddles (barrier kernels, M >= 16)
     const size_t generic_lds = (size_t)gfast * seq1;   // fallback for unaligned calls keeps the layout
-    static const int gl_env = getenv("FRBCH_GL") ? atoi(getenv("FRBCH_GL")) : 0;   // experiments: layout group = workgroup group
+#ifdef FRBCH_EXPERIMENTS
+    static const int gl_env = getenv("FRBCH_GL") ? atoi(getenv("FRBCH_GL")) : 0;   // layout group = workgroup group
+#else
+    const int gl_env = 0;
+#endif
     if (gfast <= pl->c2 && lds <= lds_limit && generic_lds <= lds_limit) {
       pl->fast_k1_log2m = ilog2(m);
       pl->fast_k1_wave = wave ? 1 : 0;
@@ -331,7 +335,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
     // into EQUAL batches (measured, 152-block scan: 64 + 64 + 24 blocks 3.60 ms per step, 3 x 51 3.61 ms, 76 + 76
     // 3.48 ms, one batch of 152 3.40-3.47 ms).
     const uint64_t spill_per_block = pl->n * 8 * (pl->coherent ? 2 : 1);
-    maxb = (uint32_t)std::max<uint64_t>(1, ((cfg.pol_mode == 4 ? 4096ull : 8192ull) << 20) / spill_per_block);
+    maxb = (uint32_t)std::max<uint64_t>(1, ((cfg.pol_mode >= 4 ? 4096ull : 8192ull) << 20) / spill_per_block);
     if (maxb > 256) maxb = 256;
   }
   if (maxb > 32768) maxb = 32768;
@@ -339,7 +343,11 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
   pl->maxb = maxb;
   // Spill slabs of one block are R*g*8 B = a power of two apart: the 2C/g pieces K2 gathers for one tile would
   // all sit on one HBM channel.  A pad per slab spreads them.
-  static const int pad_env = getenv("FRBCH_SPILL_PAD") ? atoi(getenv("FRBCH_SPILL_PAD")) : -1;   // experiments, in cf
+#ifdef FRBCH_EXPERIMENTS
+  static const int pad_env = getenv("FRBCH_SPILL_PAD") ? atoi(getenv("FRBCH_SPILL_PAD")) : -1;   // in cf
+#else
+  const int pad_env = -1;
+#endif
   // measured (K2, cfg 2): pad 0 -> 1.55 ms, 16 -> 1.38, 48..8208 -> 1.29-1.33; 272 cf = 2 KB + 128 B
   const int pad = (uint64_t)pl->r * pl->g >= 2048 ? 272 : 16;
   pl->gs = (uint64_t)pl->r * pl->g + (uint64_t)(pad_env >= 0 ? pad_env : pad);
@@ -487,6 +495,11 @@ extern "C" int frbch_config_from_hdr(const char* hdr_path, frbch_config* cfg) {
     const size_t b = val.find_first_not_of(" \t");
     val = b == std::string::npos ? "" : val.substr(b);
     while (!val.empty() && (val.back() == '\r' || val.back() == ' ' || val.back() == '\t')) val.pop_back();
+    // a value that does not fit its field is an argument error, not a silently truncated name
+    if ((key == "TELESCOPE" && val.size() >= sizeof cfg->telescope) || (key == "SOURCE" && val.size() >= sizeof cfg->source) ||
+        (key == "RA" && val.size() >= sizeof cfg->ra) || (key == "DEC" && val.size() >= sizeof cfg->dec) ||
+        (key == "DATAFILE" && val.size() >= sizeof cfg->datafile))
+      return FRBCH_E_ARG;
     if (key == "TELESCOPE") snprintf(cfg->telescope, sizeof cfg->telescope, "%s", val.c_str());
     else if (key == "SOURCE") snprintf(cfg->source, sizeof cfg->source, "%s", val.c_str());
     else if (key == "RA") snprintf(cfg->ra, sizeof cfg->ra, "%s", val.c_str());
@@ -518,6 +531,7 @@ extern "C" int frbch_parse_digifil_argv(int argc, const char* const* argv, frbch
                                         size_t out_cap, char* err, size_t err_cap) {
   if (!cfg || !argv) return FRBCH_E_ARG;
   std::string hdr, out, val;
+  bool want_iquv = false;
   for (int i = 1; i < argc; ++i) {
     const std::string tok = argv[i];
     if (tok.empty()) continue;
@@ -530,6 +544,7 @@ extern "C" int frbch_parse_digifil_argv(int argc, const char* const* argv, frbch
     if (tok == "-cont") continue;                       // contiguous input: what we assume anyway
     else if (tok == "-c") cfg->rescale_constant = 1;
     else if (tok == "-2") continue;                     // 2-bit excision off: static level table
+    else if (tok == "-iquv") want_iquv = true;          // extension: Stokes I,Q,U,V from the -d4 products (pol_mode 5)
     else if (tok == "-threads") { ok = opt_value(tok, 8, argc, argv, &i, &val); }
     else if (tok.compare(0, 2, "-b") == 0) { ok = opt_value(tok, 2, argc, argv, &i, &val); cfg->nbit_out = atoi(val.c_str()); }
     else if (tok.compare(0, 2, "-S") == 0) { ok = opt_value(tok, 2, argc, argv, &i, &val); cfg->start_s = atof(val.c_str()); }
@@ -571,6 +586,10 @@ extern "C" int frbch_parse_digifil_argv(int argc, const char* const* argv, frbch
       return FRBCH_E_ARG;
     }
     if (!ok) { set_err(err, err_cap, "option " + tok + " needs a value"); return FRBCH_E_ARG; }
+  }
+  if (want_iquv) {
+    if (cfg->pol_mode != 4) { set_err(err, err_cap, "-iquv needs -d4"); return FRBCH_E_ARG; }
+    cfg->pol_mode = 5;
   }
   if (hdr.empty()) { set_err(err, err_cap, "no input .hdr given"); return FRBCH_E_ARG; }
   if (out.empty()) { set_err(err, err_cap, "no output file (-o) given"); return FRBCH_E_ARG; }

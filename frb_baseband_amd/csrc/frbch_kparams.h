@@ -84,6 +84,9 @@ struct KParams {
                              // [blk][t/8][n1/G][t%8][n1%G] (frbch_k1_fast<5> -> frbch_k2_fast<5>: whole cache lines on both sides).
                              // Set per launch by the engine (the K1 that runs decides)
   unsigned long long* stamps; // diagnostic builds of the wave K1: s_memtime stamps [workgroup][wave][16] of one block; null = off
+  const uint32_t* fbad;       // generic K1 only: bitmap over the frames of `frames` (bit f = frame f is flagged invalid or is a
+                              // filler for a missing frame): its samples enter the filterbank as 0.  null = every frame is good
+  uint64_t fbad_frame0;       // index, inside the bitmap, of the frame `frames` points at
 };
 
 struct StatParams {

@@ -127,6 +127,7 @@ def process_scan(vdif_by_if: dict, *, freq_lsb_0: float, bw: float, nchan: int, 
     ``out_dir/<vdif basename>_pol<pol>.fil`` and, on rank 0 after ``barrier()``, splice all IFs.
 
     ``vdif_by_if``: {IF number: path}.  No data-path collective: ranks only meet at the barrier.
+    ``pol`` as run_digifil's, plus 5 = Stokes I,Q,U,V (the `-d4 -iquv` extension).
     ``direct=True``: the rank's IFs are concatenated on its GPU (``run_scan``) into one ``<out_name>.rank<r>`` piece
     and rank 0 splices the world's pieces (with one rank: the IFall file is written directly, no per-IF files).
     Returns the spliced path on rank 0, else None."""
@@ -146,8 +147,8 @@ def process_scan(vdif_by_if: dict, *, freq_lsb_0: float, bw: float, nchan: int, 
             p = plans[i]
             hdr = pv.make_hdr(source, p.freq_mhz, vdif_by_if[i], pol=pol, usb=(p.sideband == "u"), ra=ra, dec=dec, bw=bw,
                               telescope=telescope)
-            cmd = pv.digifil_command(hdr, os.path.join(out_dir, "unused.fil"), start, nsec, nchan, pol, nbit, tscrunch, 1,
-                                     0.0, False, keepBP)
+            cmd = pv.digifil_command(hdr, os.path.join(out_dir, "unused.fil"), start, nsec, nchan, min(pol, 4), nbit, tscrunch,
+                                     1, 0.0, False, keepBP, iquv=(pol == 5))
             cfg, _h, _o = digifil_args.parse(cmd, lib=lib)
             cfg.device = local_device
             chans.append(ch.Channeliser(cfg, lib))
@@ -174,7 +175,8 @@ def process_scan(vdif_by_if: dict, *, freq_lsb_0: float, bw: float, nchan: int, 
         hdr = pv.make_hdr(source, p.freq_mhz, path, pol=pol, usb=(p.sideband == "u"), ra=ra, dec=dec, bw=bw,
                           telescope=telescope)
         fil = os.path.join(out_dir, os.path.basename(hdr).replace(".hdr", ".fil"))
-        cmd = pv.digifil_command(hdr, fil, start, nsec, nchan, pol, nbit, tscrunch, 1, 0.0, False, keepBP)
+        cmd = pv.digifil_command(hdr, fil, start, nsec, nchan, min(pol, 4), nbit, tscrunch, 1, 0.0, False, keepBP,
+                                 iquv=(pol == 5))
         from . import digifil_args
         cfg, _h, out = digifil_args.parse(cmd, lib=lib)
         cfg.device = local_device

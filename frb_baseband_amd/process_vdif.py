@@ -7,10 +7,16 @@ but ``run_digifil`` drives the MI355X channeliser through the C ABI (include/frb
 launching DSPSR's digifil.  The digifil command string is still assembled (and printed) exactly as
 the reference does, because it is the contract the C-side parser is tested against.
 
-backend = "abi"  (default) in-process ctypes call into csrc/libfrbch.so
+backend = "abi"  in-process ctypes call into csrc/libfrbch.so (default of ``run_digifil`` as a library call)
 backend = "shim" runs csrc/digifil (our flag-compatible executable) as a subprocess, which keeps a
                  process whose name contains "digifil" alive per IF for base2fil.sh's `pwait`
-                 throttle (base2fil.sh:21-28)
+                 throttle (base2fil.sh:21-28).  DEFAULT OF THE COMMAND LINE (``main``), because that is how
+                 base2fil.sh launches this file (:61-64); FRBCH_BACKEND=abi selects the in-process call.
+
+Extensions (not in the reference; the argparse surface stays the reference's, golden-tested): FRBCH_IQUV=1 with
+``--pol 4`` writes Stokes I,Q,U,V instead of the coherency products (``run_digifil(..., iquv=True)``, shim flag
+``-iquv``); FRBCH_DEVICE=<n> picks the GPU; with ``--do_prepdata`` FRBCH_PREP=gpu dedisperses on the GPU
+(``prep.prepdata_gpu``) instead of launching PRESTO.
 """
 from __future__ import annotations
 
@@ -21,15 +27,11 @@ import stat
 import string
 import subprocess
 
-from .channeliser import Channeliser, InputError, RunError  # noqa: F401  (re-exported names)
+from .channeliser import Channeliser, Error, InputError, RunError  # noqa: F401  (re-exported names)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SHIM = os.path.join(_HERE, "csrc", "digifil")
 VALID_NBIT = [2, 8, 16, -32]
-
-
-class Error(Exception):
-    """Base class kept for callers that catch process_vdif.Error (process_vdif.py:227-229)."""
 
 
 def options(argv=None):
@@ -106,8 +108,9 @@ def make_hdr(psr, freq, filename, pol=2, usb=True, ra=None, dec=None, bw=16.0, t
     return hdrfile
 
 
-def digifil_command(hdr, filterbankfile, start, nsecs, nchan, pol, nbit, tscrunch, nthreads, dm, coherent, keepBP):
-    """The digifil command line of process_vdif.py:156-182, token for token."""
+def digifil_command(hdr, filterbankfile, start, nsecs, nchan, pol, nbit, tscrunch, nthreads, dm, coherent, keepBP,
+                    iquv=False):
+    """The digifil command line of process_vdif.py:156-182, token for token (``iquv`` appends the extension flag)."""
     if pol not in (0, 1, 2, 3, 4):
         raise InputError(f"pol = {pol} not implemented. Choices are 0, 1, 2, 3, 4")
     words = ["digifil", "-cont", "-c", f"-b{nbit}", f"-S{start}", f"-T{nsecs}", "-2", "-D", "0.0"]
@@ -123,11 +126,15 @@ def digifil_command(hdr, filterbankfile, start, nsecs, nchan, pol, nbit, tscrunc
             words.append(f"-F{nchan}:D")
     if keepBP:
         words.append("-I0")
+    if iquv:
+        if pol != 4:
+            raise InputError("iquv needs pol = 4 (the four products)")
+        words.append("-iquv")
     return " ".join(words)
 
 
 def run_digifil(hdr, fil_out_dir=None, start=1, nsecs=120, nchan=128, overwrite=False, pol=2, nbit=8, tscrunch=1,
-                nthreads=1, dm=0.0, coherent=False, keepBP=False, backend="abi", device=None):
+                nthreads=1, dm=0.0, coherent=False, keepBP=False, backend="abi", device=None, iquv=False):
     """Channelise the VDIF named by ``hdr`` into ``<fil_out_dir>/<hdr basename>.fil``
     (process_vdif.py:142-199).  A pre-existing FIFO at that path is written into, never removed."""
     filterbankfile = hdr.replace(".hdr", ".fil")
@@ -141,7 +148,8 @@ def run_digifil(hdr, fil_out_dir=None, start=1, nsecs=120, nchan=128, overwrite=
             os.remove(filterbankfile)
     if nbit not in VALID_NBIT:
         raise InputError(f"nbit={nbit} not in supported values of {VALID_NBIT}. ")
-    cmd = digifil_command(hdr, filterbankfile, start, nsecs, nchan, pol, nbit, tscrunch, nthreads, dm, coherent, keepBP)
+    cmd = digifil_command(hdr, filterbankfile, start, nsecs, nchan, pol, nbit, tscrunch, nthreads, dm, coherent, keepBP,
+                          iquv=iquv)
     print("running {0}".format(cmd))
     if backend == "shim":
         _run_shim(cmd, device)
@@ -222,11 +230,13 @@ def main(argv=None):
     if args.hdr_only:
         print("Not creating filterbanks. Hdr files done.")
         return 0
-    backend = os.environ.get("FRBCH_BACKEND", "abi")
+    # one process named "digifil" per IF, as base2fil.sh's pwait throttle counts them (base2fil.sh:21-28)
+    backend = os.environ.get("FRBCH_BACKEND", "shim")
     device = os.environ.get("FRBCH_DEVICE")
+    iquv = os.environ.get("FRBCH_IQUV", "0") not in ("", "0")
     filterbankfile = run_digifil(hdr, args.fil_out_dir, args.start, args.nsec, args.nchan, overwrite=args.force,
                                  pol=args.pol, nbit=args.nbit, tscrunch=args.tscrunch, nthreads=args.nthreads,
-                                 keepBP=args.keepBP, backend=backend, device=device)
+                                 keepBP=args.keepBP, backend=backend, device=device, iquv=iquv)
     if args.do_prepdata:
         dm1 = args.dm if args.dm is not None else psr_info(args.psrname)[2]
         prepdata(filterbankfile, dm1, zerodm=args.nozerodm, clip=args.clip, dm2=args.dm2, dmstep=args.dmstep,

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define FRBCH_ABI_VERSION 1
+#define FRBCH_ABI_VERSION 2
 
 /* error codes (negative); 0 = ok.  process_vdif.py:193-198 turns a non-zero digifil exit status
  * into RunError; the CLI shim maps any of these to exit status 1 with frbch_strerror on stderr. */
@@ -38,7 +38,10 @@ enum {
 
 /* pol_mode: what run_digifil maps --pol to (process_vdif.py:163-176):
  *   0,1 -> -P0/-P1 single polarisation power; 2 -> -d1 PP+QQ; 3 -> -d3 (PP+QQ)^2;
- *   4 -> -d4 PP,QQ,Re(PQ*),Im(PQ*)  (help text :58-64; base2fil.sh:214-217). */
+ *   4 -> -d4 PP,QQ,Re(PQ*),Im(PQ*)  (help text :58-64; base2fil.sh:214-217);
+ *   5 -> Stokes I,Q,U,V formed from the -d4 products for the circular feeds make_hdr declares ("BASIS Circular",
+ *        process_vdif.py:131): I = PP+QQ, Q = 2 Re(PQ*), U = 2 Im(PQ*), V = PP-QQ.  An extension (north_star "IQUV
+ *        formation"): the reference's --pol stops at 4 (:175-176); the shim spells it `-d4 -iquv`. */
 typedef struct frbch_config {
   uint32_t size;               /* = sizeof(frbch_config); versioning                          */
   uint32_t abi_version;        /* = FRBCH_ABI_VERSION                                         */
@@ -57,16 +60,16 @@ typedef struct frbch_config {
   uint32_t coherent;           /* -F<nchan>:D (process_vdif.py:179-180): dedisperse in the filterbank */
   int32_t device;              /* GPU ordinal (>= 0)                                          */
   uint32_t max_blocks_per_launch; /* 0 = auto; filterbank blocks batched per kernel launch    */
-  uint32_t flags;              /* 0 in production.  Kernel-selection switches for A/B measurements: 1 generic K1,
-                                * 2 generic K2, 4 1024-thread K2, 8 barrier (non wave-private) kernels, 16 4-sequence K2,
-                                * 32 one wave per sequence in K2, 64/128 experimental K1 shapes, 1<<20 rescale statistics in a
-                                * separate pass over the power buffer instead of inside K2, 1<<21 slab layout of the spill
-                                * where the tile-major one would be used; bits 8..19 (flags >> 8)
-                                * are timing-only ablations that produce WRONG output (used by the profiling notes).
-                                * Environment (diagnostics only): FRBCH_NO_K0 (K1 gathers from the frames instead of the
-                                * corner-turned copy), FRBCH_NO_PIPELINE (whole-file paths without reader / writer threads),
-                                * FRBCH_STAMPS=<file> (phase stamps of K1, tools_stamps.py), FRBCH_K1_STAG, FRBCH_GL,
-                                * FRBCH_SPILL_PAD, FRBCH_K2_NPERS, FRBCH_K1_MAXWG (kernel-shape experiments)          */
+  uint32_t flags;              /* 0 in production.  Kernel-selection switches, every one produces the same (correct) output and
+                                * has parity cases: 1 generic K1, 2 generic K2, 4 1024-thread K2, 8 barrier (non wave-private)
+                                * kernels, 16 4-sequence K2, 32 one wave per sequence in K2, 64/128 alternative K1 shapes,
+                                * 1<<20 rescale statistics in a separate pass over the power buffer instead of inside K2,
+                                * 1<<21 slab layout of the spill where the tile-major one would be used, 1<<22 whole-file paths
+                                * without reader / writer threads, 1<<23 K1 gathers from the frames (no corner-turned copy),
+                                * 1<<24 the previous wave K1 (one wave per 2048-point sequence) instead of the split one.
+                                * Any other bit makes frbch_open fail with FRBCH_E_ARG: bits 8..19 (timing-only ablations that
+                                * produce WRONG output) and the environment knobs of the profiling notes exist only in
+                                * libraries built with -DFRBCH_EXPERIMENTS (make EXPERIMENTS=1), never in the product build. */
   char telescope[64];          /* .hdr TELESCOPE  (process_vdif.py:123)                       */
   char source[64];             /* .hdr SOURCE     (:124)                                      */
   char ra[32];                 /* .hdr RA         (:125)                                      */
@@ -75,6 +78,9 @@ typedef struct frbch_config {
   uint32_t input_bits;         /* bits per sample of the VDIF: 2, or 1 (mode VDIF_8000-1024-16-1, spif2file.sh:58-61);
                                 * 0 = take it from the first frame header (host paths) / 2 (device paths)            */
   uint32_t reserved1;
+  float levels[4];             /* 2-bit level table, state 0..3 -> voltage (process_vdif.py:157 passes the bare `-2`: DSPSR's
+                                * static table); all four 0 = the default -3.3359, -1, +1, +3.3359.  A run-time table in
+                                * every kernel, so another level scheme is a data change.                                  */
 } frbch_config;
 
 typedef struct frbch_handle frbch_handle;
@@ -97,10 +103,13 @@ typedef struct frbch_info {
   uint32_t have_rescale;       /* offset/scale are defined                                     */
   uint32_t reserved;
   uint64_t frames_seen;        /* host streaming path: frames whose header was checked           */
-  uint64_t frames_invalid;     /* ... with the VDIF invalid bit set (data used as is: -cont)     */
-  uint64_t frame_gaps;         /* ... frame-number discontinuities (treated as contiguous: -cont) */
+  uint64_t frames_invalid;     /* ... with the VDIF invalid bit set: their samples enter the filterbank as 0 (the level table's
+                                  mean), extract_baseband_chunk.py:56-69 reads the same bit                            */
+  uint64_t frame_gaps;         /* ... frame-number discontinuities; forward jumps are filled with zero samples so that the
+                                  stream stays contiguous in time (-cont, process_vdif.py:157), see frames_filled       */
   uint64_t block_stride_bytes; /* payload bytes between block starts: = block_payload_bytes, less with -F C:D */
   uint32_t nfilt_pos, nfilt_neg; /* -F C:D overlap-save: channel samples dropped at the start / end of a block */
+  uint64_t frames_filled;      /* zero frames inserted for missing frame numbers (host paths)                              */
 } frbch_info;
 
 /* per-kernel device time accumulated since the last frbch_timing_reset (HIP events recorded on
@@ -186,6 +195,15 @@ int frbch_flush_device(frbch_handle* h, void* d_out, size_t out_cap_bytes, uint6
 int frbch_power_device(frbch_handle* h, const void* d_frames, size_t nframes, uint32_t frame_bytes,
                        uint32_t header_bytes, uint64_t payload_byte_offset, uint64_t nblocks,
                        float* d_power, size_t cap_bytes, void* stream);
+
+/* The unpack stage (A4) in isolation: `nsamples` dual-pol samples starting `payload_byte_offset` bytes into the payload
+ * stream, decoded with the handle's level table (frbch_config::levels) exactly as the filterbank's first kernel decodes
+ * them: float32 d_volt[pol][nsamples].  decoder 0 = the generic K1's decode (1- and 2-bit input); 1 = the register
+ * kernels' two decodes (nibble table of frbch_k1_wave, select chain of frbch_k1_fast; 2-bit input, nsamples even):
+ * d_volt[2][pol][nsamples].  The `-2` of process_vdif.py:157,160 selects this static table. */
+int frbch_unpack_device(frbch_handle* h, const void* d_frames, size_t nframes, uint32_t frame_bytes,
+                        uint32_t header_bytes, uint64_t payload_byte_offset, uint64_t nsamples, int decoder,
+                        float* d_volt, size_t cap_bytes, void* stream);
 
 /* ---- rescale state (the one stateful stage; SURVEY 7 hard part 6) ------------------------- */
 /* offset/scale are [nif][nchan] in INPUT channel order k (ascending FFT bin), float32 */

@@ -131,7 +131,7 @@ def strip_frames(raw: np.ndarray, frame_bytes: int, header_bytes: int) -> np.nda
 # --------------------------------------------------------------------------------------------
 # 2-bit unpack (A4): byte -> 4 floats
 # --------------------------------------------------------------------------------------------
-def unpack_2bit(payload: np.ndarray) -> np.ndarray:
+def unpack_2bit(payload: np.ndarray, levels=None) -> np.ndarray:
     """u8[nbytes] -> f64[2][2*nbytes].
 
     2-channel (= 2 pol), 2-bit VDIF: bits[1:0]=pol0 t, [3:2]=pol1 t, [5:4]=pol0 t+1,
@@ -139,11 +139,12 @@ def unpack_2bit(payload: np.ndarray) -> np.ndarray:
     2 pols x 2 bits per IF).
     """
     b = payload.astype(np.uint8)
+    lv = LEVELS_2BIT if levels is None else np.asarray(levels, dtype=np.float32).astype(np.float64)
     out = np.empty((2, b.size * 2), dtype=np.float64)
-    out[0, 0::2] = LEVELS_2BIT[b & 3]
-    out[1, 0::2] = LEVELS_2BIT[(b >> 2) & 3]
-    out[0, 1::2] = LEVELS_2BIT[(b >> 4) & 3]
-    out[1, 1::2] = LEVELS_2BIT[(b >> 6) & 3]
+    out[0, 0::2] = lv[b & 3]
+    out[1, 0::2] = lv[(b >> 2) & 3]
+    out[0, 1::2] = lv[(b >> 4) & 3]
+    out[1, 1::2] = lv[(b >> 6) & 3]
     return out
 
 
@@ -161,8 +162,8 @@ def unpack_1bit(payload: np.ndarray) -> np.ndarray:
     return out
 
 
-def unpack(payload: np.ndarray, bits: int) -> np.ndarray:
-    return unpack_1bit(payload) if bits == 1 else unpack_2bit(payload)
+def unpack(payload: np.ndarray, bits: int, levels=None) -> np.ndarray:
+    return unpack_1bit(payload) if bits == 1 else unpack_2bit(payload, levels)
 
 
 # --------------------------------------------------------------------------------------------
@@ -266,7 +267,7 @@ def filterbank_block_coherent(x: np.ndarray, nchan: int, freq_res: int, kernel: 
 # Detection (A7): -P0/-P1/-d1/-d3/-d4
 # --------------------------------------------------------------------------------------------
 def nif_for(pol_mode: int) -> int:
-    return 4 if pol_mode == 4 else 1
+    return 4 if pol_mode in (4, 5) else 1
 
 
 def detect(y: np.ndarray, pol_mode: int) -> np.ndarray:
@@ -287,6 +288,12 @@ def detect(y: np.ndarray, pol_mode: int) -> np.ndarray:
     if pol_mode == 4:
         pq = y[0] * np.conj(y[1])
         return np.stack([pp, qq, pq.real, pq.imag])
+    if pol_mode == 5:
+        # Stokes parameters of circularly polarised feeds ("BASIS Circular", process_vdif.py:131) from the -d4
+        # coherency products: I = PP+QQ, Q = 2 Re(PQ*), U = 2 Im(PQ*), V = PP-QQ.  An extension of the build
+        # (north_star "IQUV formation"); the reference itself stops at the products (:58-64,175-176).
+        pq = y[0] * np.conj(y[1])
+        return np.stack([pp + qq, 2.0 * pq.real, 2.0 * pq.imag, pp - qq])
     raise ValueError(f"pol = {pol_mode} not implemented. Choices are 0, 1, 2, 3, 4")
 
 
@@ -443,6 +450,7 @@ class Config:
     ra: str = "00:00:00.0"
     dec: str = "00:00:00.0"
     rawdatafile: str = ""
+    levels: tuple | None = None     # 2-bit level table (None = DSPSR's static one)
     fixed_offset: np.ndarray | None = None   # set_rescale equivalent
     fixed_scale: np.ndarray | None = None
     result: dict = field(default_factory=dict)
@@ -473,7 +481,7 @@ def detected_power(raw_frames: np.ndarray, cfg: Config):
     nwant = int(round(cfg.total_s * rate))
     nsamp = max(0, min(navail, nwant))
     nblocks = (nsamp - n) // hop + 1 if nsamp >= n else 0
-    x = unpack(payload[s0 // spb: s0 // spb + ((nblocks - 1) * hop + n) // spb if nblocks else s0 // spb], bits)
+    x = unpack(payload[s0 // spb: s0 // spb + ((nblocks - 1) * hop + n) // spb if nblocks else s0 // spb], bits, cfg.levels)
     out = []
     for b in range(nblocks):
         xb = x[:, b * hop: b * hop + n]

@@ -41,6 +41,7 @@ static void emu_launch(void (*k)(PT, int, int, int, unsigned char*), long gx, lo
 static inline const char* dev_last_error_string() { return "emulator"; }
 static inline int dev_count() { return 1; }
 static inline int dev_set(int) { return 0; }
+static inline int dev_get() { return 0; }
 static inline int dev_arch_ok(int, char* name, size_t cap, size_t* lds_limit) {
   snprintf(name, cap, "emu");
   *lds_limit = 160 * 1024;

@@ -26,19 +26,20 @@ def make_case(bw, nchan, secs, **kw):
 
 
 def oracle_cfg(bw, nchan, secs, pol=2, nbit=8, tscr=1, interval=10.0, const=1, freq_res=0, start=0.0,
-               dm=0.0, coherent=0, freq=1608.0):
+               dm=0.0, coherent=0, freq=1608.0, levels=None):
     return o.Config(bw_mhz=bw, nchan=nchan, total_s=secs, start_s=start, pol_mode=pol, nbit=nbit,
                     tscrunch=tscr, rescale_interval_s=interval, rescale_constant=bool(const),
                     freq_res=freq_res, source="unknown", telescope="ONSALA85", dm=dm, coherent=bool(coherent),
-                    freq_mhz=freq)
+                    freq_mhz=freq, levels=levels)
 
 
 def lib_cfg(lib, bw, nchan, secs, pol=2, nbit=8, tscr=1, interval=10.0, const=1, freq_res=0, start=0.0, maxb=0, flags=0,
-            dm=0.0, coherent=0, freq=1608.0):
+            dm=0.0, coherent=0, freq=1608.0, levels=None):
+    kw = {} if levels is None else {"levels": levels}
     return ch.new_config(lib, bw_mhz=bw, nchan=nchan, total_s=secs, start_s=start, pol_mode=pol,
                          nbit_out=nbit, tscrunch=tscr, rescale_interval_s=interval,
                          rescale_constant=const, freq_res=freq_res, max_blocks_per_launch=maxb, flags=flags,
-                         dm=dm, coherent=coherent, freq_mhz=freq)
+                         dm=dm, coherent=coherent, freq_mhz=freq, **kw)
 
 
 def expected_boundary_distance(ocfg):

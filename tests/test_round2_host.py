@@ -1,0 +1,130 @@
+"""Round-2 host-side checks that need no GPU: ABI v2 fields, flag hygiene, error classes, the IQUV and level-table
+extensions and the unpack tap through the TEST-ONLY emulator build, scan buffer sizing of the push-driven fallback."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from frb_baseband_amd import _lib, channeliser as ch, digifil_args, multi_if, process_vdif as pv, sigproc, synth, vdif
+from oracle import frb_oracle as o
+from tests import parity_util as pu
+
+
+def test_error_classes_share_the_reference_base():
+    """process_vdif.py:227-255: InputError and RunError derive from Error"""
+    assert issubclass(pv.InputError, pv.Error) and issubclass(pv.RunError, pv.Error)
+    with pytest.raises(pv.Error):
+        pv.run_digifil("/d/x.hdr", "/fifo", overwrite=True, nbit=7)
+    with pytest.raises(pv.Error):
+        raise pv.RunError("x")
+    assert pv.Error is ch.Error
+
+
+def test_iquv_is_an_extension_not_a_change_of_the_reference_surface():
+    with pytest.raises(pv.InputError, match="pol = 5 not implemented"):       # golden message, unchanged
+        pv.digifil_command("/d/x.hdr", "/o/x.fil", 0, 1, 128, 5, 8, 1, 1, 0.0, False, False)
+    cmd = pv.digifil_command("/d/x.hdr", "/o/x.fil", 0, 1, 128, 4, 8, 1, 1, 0.0, False, False, iquv=True)
+    assert cmd.endswith("-d4 -F128:512 -iquv")
+    cfg, _h, _o = digifil_args.parse(cmd, read_hdr=False)
+    assert cfg.pol_mode == 5
+    with pytest.raises(ch.InputError, match="-iquv needs -d4"):
+        digifil_args.parse(cmd.replace("-d4", "-d1"), read_hdr=False)
+    with pytest.raises(pv.InputError):
+        pv.digifil_command("/d/x.hdr", "/o/x.fil", 0, 1, 128, 2, 8, 1, 1, 0.0, False, False, iquv=True)
+
+
+def test_hdr_values_that_do_not_fit_are_argument_errors(tmp_path, hip_lib):
+    long_name = str(tmp_path / ("d" * 600 + ".vdif"))
+    hdr = tmp_path / "x.hdr"
+    hdr.write_text("HDR_VERSION 0.1\nTELESCOPE  Ef\nSOURCE     R3\nRA         01:00:00\nDEC        02:00:00\n"
+                   "FREQ       1400.0\nBW         32.0\nDATAFILE   %s\nINSTRUMENT VDIF\nNPOL       2" % long_name)
+    cfg = ch.new_config(hip_lib)
+    assert hip_lib.frbch_config_from_hdr(str(hdr).encode(), C.byref(cfg)) == _lib.E_ARG
+
+
+def test_unknown_flag_bits_are_rejected(emu_lib):
+    for bad in (1 << 8, 1 << 12, 1 << 19, 1 << 25, 1 << 31):
+        with pytest.raises(ch.InputError, match="unknown bit"):
+            ch.Channeliser(ch.new_config(emu_lib, flags=bad), emu_lib)
+    ch.Channeliser(ch.new_config(emu_lib, flags=(1 << 20) | (1 << 22)), emu_lib).close()
+
+
+def test_product_library_is_not_an_experiments_build(hip_lib):
+    assert b"experiments" not in hip_lib.frbch_version()
+    assert b"abi 2" in hip_lib.frbch_version()
+
+
+@pytest.mark.parametrize("bw,nchan,secs,kw", [
+    (16.0, 32, 0.03, dict(pol=5, freq_res=64)),                      # IQUV through the generic K2
+    (-16.0, 32, 0.03, dict(pol=5, freq_res=64, nbit=-32, tscr=4)),
+    (16.0, 16, 0.012, dict(pol=5, dm=1.0, coherent=1, freq=316.0)),  # ... through K3 / K4
+    (16.0, 32, 0.03, dict(freq_res=64, levels=(-2.75, -0.5, 0.25, 4.5))),
+])
+def test_extensions_match_the_oracle_on_the_emulator(emu_lib, bw, nchan, secs, kw):
+    pu.run_streaming_case(emu_lib, bw, nchan, secs, **kw)
+
+
+def test_stokes_relations_hold_between_the_two_four_product_modes(emu_lib):
+    raw = synth.make_vdif(0.03, bw_mhz=16.0, nchan=32)
+    out = {}
+    for pol in (4, 5):
+        with ch.Channeliser(pu.lib_cfg(emu_lib, 16.0, 32, 0.03, pol=pol, nbit=-32, interval=0.0, freq_res=64), emu_lib) as c:
+            out[pol] = sigproc.read_fil(c.channelise_bytes(raw)).data.astype(np.float64)
+    pp, qq, re, im = (out[4][:, i] for i in range(4))
+    i_, q_, u_, v_ = (out[5][:, i] for i in range(4))
+    np.testing.assert_allclose(i_, pp + qq, rtol=1e-6)
+    np.testing.assert_allclose(v_, pp - qq, rtol=0, atol=1e-6 * np.abs(pp + qq).max())
+    np.testing.assert_allclose(q_, 2 * re, rtol=0, atol=1e-6 * np.abs(pp + qq).max())
+    np.testing.assert_allclose(u_, 2 * im, rtol=0, atol=1e-6 * np.abs(pp + qq).max())
+    assert np.all(i_ * i_ + 1e-3 >= q_ * q_ + u_ * u_ + v_ * v_ - 1e-6 * i_ * i_)     # |polarised| <= I
+
+
+def test_unpack_tap_all_byte_values_on_the_emulator(emu_lib):
+    """decoder 0 (the generic K1's decode) over all 256 byte values, 2-bit and 1-bit, default and custom tables"""
+    payload = (np.arange(16000, dtype=np.uint32) * 37 % 256).astype(np.uint8)
+    payload[:256] = np.arange(256, dtype=np.uint8)
+    for bits, levels in ((2, None), (2, (-2.75, -0.5, 0.25, 4.5)), (1, None)):
+        raw = vdif.frame_payload(payload, bw_mhz=32.0, bits=bits)
+        nsamp = payload.size * (4 // bits)
+        kw = {} if levels is None else {"levels": levels}
+        with ch.Channeliser(ch.new_config(emu_lib, bw_mhz=32.0, nchan=64, input_bits=bits, **kw), emu_lib) as c:
+            volt = np.zeros((2, nsamp), np.float32)
+            c.unpack_device(raw.ctypes.data, 2, 8032, 32, 0, nsamp, 0, volt.ctypes.data, volt.nbytes)
+            with pytest.raises(ch.InputError):
+                c.unpack_device(raw.ctypes.data, 2, 8032, 32, 0, nsamp + 8, 0, volt.ctypes.data, volt.nbytes)
+        lv32 = np.array([-3.3359, -1.0, 1.0, 3.3359], np.float32) if levels is None else levels
+        want = (o.unpack_2bit(payload, lv32) if bits == 2 else o.unpack_1bit(payload)).astype(np.float32)
+        assert np.array_equal(volt, want), (bits, levels)
+
+
+def test_push_driven_scan_with_small_blocks_and_an_early_interval(emu_lib, tmp_path):
+    """frbch_run_scan without reader / writer threads (flag 1<<22): one 32-MB push is many small batches; a
+    -c interval that completes in the first of them must not overflow the scan's row buffer"""
+    d = str(tmp_path)
+    raws, vd = {}, {}
+    for i in (1, 2):
+        raws[i] = synth.make_vdif(0.3, bw_mhz=16.0, nchan=32, if_index=i)
+        vd[i] = os.path.join(d, f"x_ef_no0001_IF{i}.vdif")
+        raws[i].tofile(vd[i])
+    chans, parts = [], []
+    for i in (2, 1):
+        plan = multi_if.plan_ifs(2, 1340.0, 16.0)[i - 1]
+        bw = 16.0 if plan.sideband == "u" else -16.0
+        chans.append(ch.Channeliser(ch.new_config(emu_lib, bw_mhz=bw, freq_mhz=plan.freq_mhz, nchan=32, freq_res=64, total_s=0.3,
+                                                  rescale_constant=1, rescale_interval_s=0.002, max_blocks_per_launch=8,
+                                                  flags=1 << 22), emu_lib))
+        cfg = o.Config(bw_mhz=bw, freq_mhz=plan.freq_mhz, nchan=32, freq_res=64, total_s=0.3, rescale_interval_s=0.002,
+                       source="unknown")
+        parts.append(sigproc.read_fil(o.channelise(raws[i], cfg)))
+    out = os.path.join(d, "IFall.fil")
+    try:
+        multi_if.run_scan(chans, [vd[2], vd[1]], out)
+    finally:
+        for c in chans:
+            c.close()
+    got = sigproc.read_fil(out)
+    want = np.concatenate([p.data for p in parts], axis=2)
+    assert got.data.shape == want.shape
+    assert np.abs(got.data.astype(int) - want.astype(int)).max() <= 1
+    assert np.count_nonzero(got.data != want) <= 1e-4 * want.size
