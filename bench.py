@@ -9,8 +9,16 @@ configs[1]: 1 IF, 32 MHz, 2-bit dual-pol -> 1024-channel Stokes-I (digifil flags
 path shards by IF, base2fil.sh:60-66: no collective on the data path) -> weak scaling.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  "roofline":     dominant kernel's algorithmic bytes / its HIP-event time vs the 8 TB/s HBM peak
-  "cpu_baseline": the CPU oracle port timed on a bounded sample of the same workload (rank 0, N=1)
+  "roofline":       dominant kernel's algorithmic bytes / its HIP-event time vs the 8 TB/s HBM peak; "traffic" = HBM bytes
+                    per launch of that kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE: separate passes, gfx950
+                    x2 correction of wide fetches) collected LIVE by child processes of this very run (N = 1), else null
+  "cpu_baseline":   the CPU oracle port timed on a bounded sample of the same workload (rank 0, N=1)
+  "host_inclusive": the product call the reference makes (frbch_run_file: VDIF file -> .fil file, both on tmpfs) for the
+                    same workload, PCIe both ways included -- never `value`
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process only LAUNCHES N fresh rank processes (before any
+GPU call; it never touches the GPU itself), forwards rank 0's JSON line and exits non-zero if a rank failed.  Under
+torch.distributed.run (the driver's way) WORLD_SIZE is set and the process is a rank.
 """
 from __future__ import annotations
 
@@ -111,7 +119,7 @@ def cpu_baseline(seconds_budget: float, bw: float, nchan: int):
             "sample": f"{nblk} filterbank blocks of {n} dual-pol samples, numpy fp64 oracle (pocketfft), 1 thread"}
 
 
-def main():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -121,6 +129,7 @@ def main():
     ap.add_argument("--nchan", type=int, default=1024)
     ap.add_argument("--bw", type=float, default=32.0)
     ap.add_argument("--pol", type=int, default=2)
+    ap.add_argument("--tscrunch", type=int, default=1)
     ap.add_argument("--dm", type=float, default=0.0)
     ap.add_argument("--coherent", action="store_true", help="-F C:D: coherent dedispersion inside the filterbank (cfg 5)")
     ap.add_argument("--freq", type=float, default=1608.0, help="centre sky frequency, MHz (matters with --coherent)")
@@ -128,16 +137,171 @@ def main():
     ap.add_argument("--maxb", type=int, default=0, help="filterbank blocks per kernel launch (0 = library default)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--flags", type=int, default=0, help="debug flags of frbch_config (see include/frbch.h)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
-    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
-    args = ap.parse_args()
+    ap.add_argument("--no-host", action="store_true", help="skip the host-inclusive (frbch_run_file) leg")
+    ap.add_argument("--host-runs", type=int, default=3, help="timed frbch_run_file passes of the host-inclusive leg")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the live PMC passes (roofline.traffic = null)")
+    ap.add_argument("--flags", type=int, default=0, help="kernel-selection flags of frbch_config (see include/frbch.h)")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo with --share-gpu)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a one-GPU box: every rank uses cuda:0 (gloo)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # run under rocprofv3 by collect_traffic
+    return ap
 
-    import torch
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """--gpus N without WORLD_SIZE: start N fresh rank processes (one per GPU, like one digifil per IF,
+    base2fil.sh:60-66).  This parent never initialises the GPU; a failing rank fails the run (no re-exec, no retry)."""
+    import subprocess
+    n = args.gpus
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(0 if args.share_gpu else r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0 = procs[0].communicate()[0]
+    rcs = [procs[0].returncode] + [pr.wait() for pr in procs[1:]]
+    if any(rcs):
+        print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
+        sys.stdout.write(out0 or "")
+        return 1
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return 0
+
+
+WIDE_FETCH = ("frbch_k2_", "frbch_quantise", "frbch_stats_partial", "frbch_k0_stage", "frbch_k1_wave", "frbch_k1_split")
+
+
+def collect_traffic(argv):
+    """HBM bytes per launch of every frbch kernel, measured NOW: two child runs of this script under rocprofv3
+    (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`: the counters do not fit one pass, MI355X_MICROARCH.md "rocprofv3 PMC slots").
+    FETCH_SIZE is doubled for kernels that read with 16-byte-per-lane loads (gfx950 tallies 128-B requests at 64 B, same
+    guide, "HBM").  The caller has not touched the GPU yet.  Any failure -> None (the bench line then says traffic null)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    child = [a for a in argv if a not in ("--pmc-child",)]
+    res = {}
+    tmp = tempfile.mkdtemp(prefix="frbch_pmc_", dir="/tmp")
+    try:
+        for cnt in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, cnt)
+            cmd = ["rocprofv3", "--pmc", cnt, "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.abspath(__file__)] + child + ["--pmc-child"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            pr = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+            if pr.returncode != 0:
+                return None
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None
+            for path in files:
+                for row in csv.DictReader(open(path)):
+                    if row.get("Counter_Name") != cnt or "frbch" not in row.get("Kernel_Name", ""):
+                        continue
+                    k = row["Kernel_Name"]
+                    rec = res.setdefault(k, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "n": {}})
+                    rec[cnt] += float(row["Counter_Value"])
+                    rec["n"][cnt] = rec["n"].get(cnt, 0) + 1
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = {"_source": "live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run (KB counters; wide fetches x2)"}
+    import re
+    for k, rec in res.items():
+        m = re.search(r"(frbch_[a-z0-9_]+)(<[^>]*>)?", k)
+        if not m:
+            continue
+        short = (m.group(1) + (m.group(2) or "")).replace(" ", "")
+        short = re.sub(r",(true|false)>", ">", short)     # the engine's slot name carries no staging / statistics flag
+        nl = max(1, min(rec["n"].get("FETCH_SIZE", 1), rec["n"].get("WRITE_SIZE", 1)))
+        corr = 2.0 if short.startswith(WIDE_FETCH) else 1.0
+        out[short] = (rec["FETCH_SIZE"] / max(1, rec["n"].get("FETCH_SIZE", 1)) * corr +
+                      rec["WRITE_SIZE"] / max(1, rec["n"].get("WRITE_SIZE", 1))) * 1024.0
+        out.setdefault("_launches", {})[short] = nl
+    return out
+
+
+PCIE_PEAK_GBS = 64.0   # PCIe Gen5 x16, one direction (MI355X_MICROARCH.md host link)
+
+
+def host_inclusive(args, torch, dist, ch, cfg_kwargs, frames, nfr, rank, world, samples_per_step):
+    """What the reference's call does end to end (process_vdif.py:191 `digifil ... -o out hdr`): frbch_run_file from a
+    VDIF file to a .fil file, both on tmpfs -- disk excluded, PCIe both ways and the host threads included."""
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+    vd = os.path.join(base, f"frbch_bench_{os.getpid()}_if{rank}.vdif")
+    fil = vd.replace(".vdif", ".fil")
+    try:
+        frames[: nfr * 8032].cpu().numpy().tofile(vd)
+        in_bytes = os.path.getsize(vd)
+        times = []
+        with ch.Channeliser(ch.new_config(**cfg_kwargs)) as c:
+            for i in range(args.host_runs + 1):          # first pass untimed: pinned buffers, page cache, clocks
+                c.reset()
+                if dist is not None:
+                    dist.barrier()
+                t0 = time.perf_counter()
+                c.run_file(vd, fil)
+                dt = time.perf_counter() - t0
+                if dist is not None:
+                    t = torch.tensor([dt], dtype=torch.float64, device=frames.device if args.backend == "nccl" else "cpu")
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    dt = float(t.item())
+                if i:
+                    times.append(dt)
+        out_bytes = os.path.getsize(fil)
+        best = sorted(times)[len(times) // 2]
+        each_way = max(in_bytes, out_bytes) / best / 1e9
+        return {"value": round(samples_per_step * world / best / 1e6, 1), "unit": "Msamples/s", "s_per_scan": round(best, 4),
+                "realtime_x": round(samples_per_step / best / 1e6 / (2 * args.bw), 1),
+                "bytes_in_per_if": in_bytes, "bytes_out_per_if": out_bytes,
+                "pcie": {"bound": "pcie", "achieved": round(each_way, 2), "peak": PCIE_PEAK_GBS, "unit": "GB/s per direction per GPU",
+                         "frac": round(each_way / PCIE_PEAK_GBS, 4)},
+                "path": f"frbch_run_file: {base} VDIF -> pinned ring -> HBM -> pinned ring -> {base} .fil, median of {len(times)} scans after one untimed"}
+    except Exception as exc:   # a reported extra: never fail the bench for it
+        return {"error": repr(exc)}
+    finally:
+        for f in (vd, fil):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+
+
+def main():
+    args = build_parser().parse_args()
+    argv = sys.argv[1:]
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        sys.exit(launch_ranks(args, argv))          # parent: launches only, never touches the GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    world = int(world_env or "1")
+    if args.backend is None:
+        args.backend = "gloo" if args.share_gpu else "nccl"
+
+    # live PMC passes first: the children must start before this process initialises the GPU
+    live_traffic = None
+    if world == 1 and not args.no_traffic and not args.pmc_child:
+        live_traffic = collect_traffic(argv + ["--steps", "1", "--warmup", "1", "--no-cpu", "--no-host", "--no-traffic"])
+    if args.pmc_child:
+        args.steps, args.warmup, args.no_cpu, args.no_host = 1, 1, True, True
+
+    import torch
+    if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -153,10 +317,11 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from frb_baseband_amd import channeliser as ch
-    cfg = ch.new_config(bw_mhz=args.bw, nchan=args.nchan, pol_mode=args.pol, nbit_out=8, tscrunch=1,
-                        rescale_constant=1, rescale_interval_s=10.0, total_s=args.seconds, device=local_rank,
-                        max_blocks_per_launch=args.maxb, flags=args.flags, dm=args.dm,
-                        coherent=1 if args.coherent else 0, freq_mhz=args.freq, freq_res=args.freq_res)
+    cfg_kwargs = dict(bw_mhz=args.bw, nchan=args.nchan, pol_mode=args.pol, nbit_out=8, tscrunch=args.tscrunch,
+                      rescale_constant=1, rescale_interval_s=10.0, total_s=args.seconds, device=local_rank,
+                      max_blocks_per_launch=args.maxb, flags=args.flags, dm=args.dm,
+                      coherent=1 if args.coherent else 0, freq_mhz=args.freq, freq_res=args.freq_res)
+    cfg = ch.new_config(**cfg_kwargs)
     c = ch.Channeliser(cfg)
     info = c.info
     frames, nfr = synth_frames_device(torch, dev, args.seconds, args.bw, args.nchan, if_index=rank)
@@ -168,7 +333,7 @@ def main():
     samples_per_step = nblocks * info.block_stride_bytes * 2      # new dual-pol samples consumed (2-bit: 2 per byte)
 
     def step():
-        c.reset()
+        c.reset()     # (waits for the previous step's work on `stream` before it touches the rescale state)
         r1 = c.process_device(frames.data_ptr(), nfr, 8032, 32, 0, nblocks, out.data_ptr(), out.numel(), stream)
         r2 = c.flush_device(out.data_ptr() + r1 * info.row_bytes, out.numel() - r1 * info.row_bytes, stream)
         return r1 + r2
@@ -189,12 +354,19 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     assert got_rows == rows, (got_rows, rows)
+    dt_rank = dt
+    per_rank = None
     if dist is not None:
-        tmax = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        red_dev = dev if args.backend == "nccl" else "cpu"
+        tall = [torch.zeros(1, dtype=torch.float64, device=red_dev) for _ in range(world)]
+        dist.all_gather(tall, torch.tensor([dt], device=red_dev, dtype=torch.float64))
+        per_rank = [float(t.item()) for t in tall]
+        dt = max(per_rank)
 
     timing = c.get_timing()
+    if args.pmc_child:
+        c.close()
+        return
     # extra (not `value`): steady state of a long scan -- scale frozen after the first interval (-c), K2 digitises in-kernel
     c.set_profiling(False)
     off, sc = c.get_rescale()
@@ -207,49 +379,54 @@ def main():
         c.process_device(frames.data_ptr(), nfr, 8032, 32, 0, nblocks, out.data_ptr(), out.numel(), stream)
     torch.cuda.synchronize()
     steady = samples_per_step * args.steps / (time.perf_counter() - t1) / 1e6
+    c.close()
+    del out
+    host = None
+    if not args.no_host:
+        host = host_inclusive(args, torch, dist, ch, cfg_kwargs, frames, nfr, rank, world, samples_per_step)
     if rank == 0:
         total_samples = samples_per_step * args.steps * world
         value = total_samples / dt / 1e6
         dom = max(timing.items(), key=lambda kv: kv[1]["total_ms"])
         name, rec = dom
         ach = rec["algorithmic_bytes"] / (rec["total_ms"] * 1e-3) / 1e9 if rec["total_ms"] > 0 else 0.0
-        # measured HBM bytes per launch of that kernel: PMC passes (FETCH_SIZE / WRITE_SIZE, collected
-        # separately with rocprofv3 by tools_profile.sh) stored per filterbank block in profiles/hbm_traffic.json
+        # measured HBM bytes per launch of that kernel: live PMC passes of this run (collect_traffic), never a stored constant
         traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-            rec_t = tj["kernels"].get(name)
-            if rec_t and args.nchan == 1024 and args.bw == 32.0 and args.pol == 2 and args.flags == 0 and not args.coherent:
-                per_block = (rec_t["fetch_kb_per_block"] * rec_t["fetch_correction"] + rec_t["write_kb_per_block"]) * 1024.0
-                traffic = per_block * nblocks * args.steps / max(1, rec["launches"])
-        except Exception:
-            traffic = None
+        if live_traffic and name in live_traffic:
+            traffic = live_traffic[name]
         roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "traffic_source": (live_traffic or {}).get("_source"),
                 "avg_launch_ms": round(rec["total_ms"] / max(1, rec["launches"]), 5),
                 "algorithmic_bytes_per_launch": rec["algorithmic_bytes"] / max(1, rec["launches"]),
-                "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in timing.items()}}
+                "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in timing.items()},
+                "whole_path": {"algorithmic_bytes_per_sample": 17.0 if args.pol < 4 else 18.5,
+                               "achieved": round(value / world * 1e6 * (17.0 if args.pol < 4 else 18.5) / 1e9, 1),
+                               "frac": round(value / world * 1e6 * (17.0 if args.pol < 4 else 18.5) / 1e9 / HBM_PEAK_GBS, 4)}}
+        prod = {2: "Stokes-I", 4: "coherency (-d4)", 5: "IQUV"}.get(args.pol, "pol%d" % args.pol)
+        dflag = {2: "-d1", 3: "-d3", 4: "-d4", 5: "-d4 -iquv"}.get(args.pol, "-P%d" % args.pol)
         line = {
             "metric": "Msamples/s channelised to .fil per GPU; achieved HBM GB/s vs peak",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{world} IF x {args.bw:g} MHz 2-bit dual-pol VDIF -> {args.nchan}-ch "
-                                   f"{'Stokes-I' if args.pol == 2 else 'pol%d' % args.pol} 8-bit .fil "
-                                   f"(-c -b8 -d1 -F{args.nchan}:{info.freq_res}"
+                                   f"{prod} 8-bit .fil "
+                                   f"(-c -b8 {dflag}{' -t %d' % args.tscrunch if args.tscrunch > 1 else ''} -F{args.nchan}:{info.freq_res}"
                                    f"{' -D %g -F%d:D' % (args.dm, args.nchan) if args.coherent else ''}), {args.seconds:g} s per IF per step, "
-                                   f"one IF per GPU, first rescale interval measured every step",
+                                   f"one IF per GPU (no data-path collective), first rescale interval measured every step, frames and .fil rows resident in HBM",
                        "samples_per_step_per_gpu": samples_per_step, "blocks_per_step": nblocks,
                        "realtime_x": round(value / world / (2 * args.bw), 2),
-                       "steady_state_msamples_per_gpu": round(steady, 1)},
+                       "steady_state_msamples_per_gpu": round(steady, 1),
+                       "per_rank_seconds": per_rank},
             "roofline": roof,
+            "host_inclusive": host,
         }
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.bw, args.nchan)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    c.close()
     if dist is not None:
         dist.destroy_process_group()
 

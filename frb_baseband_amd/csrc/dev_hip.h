@@ -12,8 +12,22 @@
   const int bx = blockIdx.x, by = blockIdx.y, nthr = blockDim.x
 #define PHASE for (int tid = threadIdx.x, once_ = 1; once_; once_ = 0)
 #define SYNC __syncthreads()
-#define FMUL_RN(a, b) __fmul_rn((a), (b))
-#define FADD_RN(a, b) __fadd_rn((a), (b))
+// Separately rounded fp32 product and sum for the rescale / digitiser arithmetic (the C expression
+// `x * digi_scale + digi_mean` of a CPU build).  HIP's __fmul_rn / __fadd_rn are plain `*` / `+` and hipcc contracts
+// them into one FMA (found by the bit-exact digitiser test: codes at exact .5 ties came out one lower); these do not
+// carry the `contract` flag, so the backend cannot fuse them.
+static __device__ __forceinline__ float frbch_fmul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  const float r = a * b;
+  return r;
+}
+static __device__ __forceinline__ float frbch_fadd_rn(float a, float b) {
+#pragma clang fp contract(off)
+  const float r = a + b;
+  return r;
+}
+#define FMUL_RN(a, b) frbch_fmul_rn((a), (b))
+#define FADD_RN(a, b) frbch_fadd_rn((a), (b))
 // streaming (read-once / write-once) 16-byte accesses
 typedef float frbch_nf4 __attribute__((ext_vector_type(4)));
 #define LOAD_F4_STREAM(dst, ptr)                                                   \

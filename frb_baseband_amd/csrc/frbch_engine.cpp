@@ -58,6 +58,7 @@ struct frbch_handle {
   // constant tables
   cf *tw_r = nullptr, *tw_c2 = nullptr, *tw_nhi = nullptr, *tw_nlo = nullptr;
   cf *ftw1_r = nullptr, *ftw2_r = nullptr, *ftw1_c = nullptr, *ftw2_c = nullptr, *td1 = nullptr, *td2 = nullptr;
+  cf *ftw1_h = nullptr, *ftw2_h = nullptr;
   // per-launch work buffers
   cf *spill = nullptr, *s_dc = nullptr, *p0 = nullptr;
   // coherent dedispersion (-F C:D): second spill, kernel table, channel-major power
@@ -218,6 +219,8 @@ KParams base_params(const frbch_handle* h) {
   p.tw_nlo = h->tw_nlo;
   p.ftw1_r = h->ftw1_r;
   p.ftw2_r = h->ftw2_r;
+  p.ftw1_h = h->ftw1_h;
+  p.ftw2_h = h->ftw2_h;
   p.ftw1_c = h->ftw1_c;
   p.ftw2_c = h->ftw2_c;
   p.td1 = h->td1;
@@ -472,6 +475,15 @@ bool launch_k1_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
     if (h->stg_ready) q.stg = h->stg;   // launch_k0_stage has corner-turned this batch
     h->stg_ready = false;
     q.tile_major = p.tile_major = pl.spill_tile_major == 2 ? 2 : 0;   // (K2 of this batch reads what this launch writes)
+    if (pl.fast_k1_split && q.stg) {    // persistent over blocks, one 16-wave workgroup per CU
+      q.nblk = nb;
+      const uint32_t ngrp = (uint32_t)(pl.c2 / 8);
+      const uint32_t ny = std::max<uint32_t>(1, std::min<uint32_t>(nb, 256u / std::max<uint32_t>(1, ngrp)));
+      hipLaunchKernelGGL(fast::frbch_k1_split, dim3(ngrp, ny), dim3(1024), pl.k1_split_lds, s, q);
+      h->kname[KID_K1] = "frbch_k1_split";
+      return true;
+    }
+    if (pl.fast_k1_split) h->kname[KID_K1] = "frbch_k1_wave<3,8,1>";
     switch (pl.fast_k1_log2m) {
       case 1: launch_k1_wave_t<1>(pl, q, nb, s); break;
       case 2: launch_k1_wave_t<2>(pl, q, nb, s); break;
@@ -622,6 +634,12 @@ int setup_fast(frbch_handle* h) {
       }
     }
     if ((rc = upload_cf(h, &h->td1, d1)) || (rc = upload_cf(h, &h->td2, d2))) return rc;
+    if (pl.fast_k1_split) {
+      std::vector<float> h1, h2;
+      fft_tables(pl.r / 2, &h1, &h2);
+      if ((rc = upload_cf(h, &h->ftw1_h, h1)) || (rc = upload_cf(h, &h->ftw2_h, h2))) return rc;
+      if ((rc = allow_lds(h, fast::frbch_k1_split, pl.k1_split_lds))) return rc;
+    }
     if (!h->stg)
       CHECK_DEV(h, dev_malloc((void**)&h->stg, (size_t)pl.maxb * pl.block_payload_bytes), "hipMalloc(staged payload)");
 #define FRBCH_AL(L, NWV, WPSV) do { if (!rc) rc = allow_lds(h, fast::frbch_k1_wave<L, NWV, WPSV, false>, pl.k1_fast_lds); \
@@ -1113,6 +1131,7 @@ extern "C" void frbch_close(frbch_handle* h) {
   if (h->stream) (void)dev_sync(h->stream);
   drain_events(h);
   dev_free(h->tw_r); dev_free(h->tw_c2); dev_free(h->tw_nhi); dev_free(h->tw_nlo);
+  dev_free(h->ftw1_h); dev_free(h->ftw2_h);
   dev_free(h->ftw1_r); dev_free(h->ftw2_r); dev_free(h->ftw1_c); dev_free(h->ftw2_c); dev_free(h->td1); dev_free(h->td2);
   dev_free(h->spill); dev_free(h->s_dc); dev_free(h->p0);
   dev_free(h->spill2); dev_free(h->chirp); dev_free(h->ptmp);

@@ -272,6 +272,14 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
     }
   }
 
+  // R = 2048, flag bit 24: the split K1 (bin-parity halves, 16 independent waves per CU) instead of the paired-branch wave
+  // K1 whenever frbch_k0_stage has corner-turned the batch (measured slower: 1.76 vs 1.54 ms)
+  pl->fast_k1_split = 0;
+  pl->k1_split_lds = (size_t)2 * 8 * (1024 + 128 + 2) * 8 + 2048 * 4 + (16 + 8 * 16 + 32) * 8;
+  if (pl->fast_k1_wave && pl->fast_k1_log2m == 3 && pl->fast_k1_kind == 0 && pl->fast_k1_g == 8 && pl->g == 8 &&
+      (cfg.flags & (1u << 24)) && pl->k1_split_lds <= lds_limit)
+    pl->fast_k1_split = 1;
+
   // tile-major spill: the paired-branch wave K1 (R = 2048, 8 branches per workgroup) in front of a wave K2 whose
   // workgroup takes two time samples (measured: K2 1.34 -> 1.29 ms, its gather alone 1.06 -> 0.95 ms; K1 unchanged)
   pl->spill_tile_major = 0;

@@ -48,6 +48,8 @@ struct Plan {
   int coh_nt;                 // threads per K3 workgroup: 1024, or 512 at R = 4096 (74 KB of LDS: two workgroups per CU)
   int fast_k2_nt;             // threads per K2 workgroup (512 / 1024)
   size_t k1_fast_lds, k2_fast_lds;
+  int fast_k1_split;          // 1 = frbch_k1_split (R = 2048, staged input): 16 independent waves per CU; falls back to the wave K1
+  size_t k1_split_lds;
   int fast_k1_g;              // branches per wave-private K1 workgroup (<= g)
   int fast_k1_kind;           // M = 8 only: 0 = 8 waves x 8 branches, 1 = 4 waves x 4 branches, 2 = 8 waves x 4 branches (2 waves/seq)
   int fast_k2_nw;             // waves per wave-private K2 workgroup (2 or 4)

@@ -48,6 +48,8 @@ struct KParams {
   // fast-path tables (kernels_fast.inc): L = 256*M, TPS = 16*M
   const cf* ftw1_r;         // [16][R/16]   exp(-2 pi i p ka / R)
   const cf* ftw2_r;         // [M][16]      exp(-2 pi i c kb / (R/16))
+  const cf* ftw1_h;         // same two tables for length R/2 (frbch_k1_split: half transforms)
+  const cf* ftw2_h;
   const cf* ftw1_c;         // same for the across-branch length 2C
   const cf* ftw2_c;
   const cf* td1;            // [2C][16]     exp(-2 pi i n1 kc / (16*2C))      (delay, coarse part)

@@ -6,13 +6,15 @@ from frb_baseband_amd import sigproc, synth
 from oracle import frb_oracle as o
 
 # Tolerances (stated, see DESIGN.md "Parity"):
-#  * detected power: |P - P_oracle| <= POWER_RTOL * mean power of that (product, channel) series
-#    (fp32 FFT of up to 2^26 points against an fp64 oracle).
+#  * detected power: |P - P_oracle| <= POWER_RTOL * mean TOTAL power (PP+QQ) of that channel's series (fp32 FFTs of
+#    2^17 .. 2^26 points against an fp64 oracle).  Measured maxima on MI355X (tests/test_gpu_pins.py::
+#    test_power_error_distribution, profiles/r02_power_error_distribution.jsonl): 1.3e-6 .. 5.2e-6 over the BASELINE
+#    configurations, i.e. median 2-4 / 99.9 % ~ 20 fp32 ULP of the oracle value for Stokes I; the bound is 2x the largest.
 #  * digitised codes: identical except where the oracle's pre-rounding value lies within
 #    TIE_EPS_SIGMA (in units of the rescaled sigma, i.e. TIE_EPS_SIGMA * digi_scale code units:
 #    2e-3 of an 8-bit code, 0.5 of a 16-bit code) of a rounding boundary; such samples may differ
 #    by 1 and must stay below MISMATCH_FRAC_PER_SIGMA * digi_scale of all samples (2e-4 for 8 bit).
-POWER_RTOL = 2e-5
+POWER_RTOL = 1.1e-5
 TIE_EPS_SIGMA = 1.0e-4
 MISMATCH_FRAC_PER_SIGMA = 1.0e-5
 CODE_TIE_EPS = TIE_EPS_SIGMA * 127.5 / 6.0          # 8-bit values, kept for reference
@@ -58,8 +60,22 @@ def check_codes(ref_bytes, got_bytes, ocfg):
     assert ref_bytes[:fr.header_bytes] == got_bytes[:fg.header_bytes], "SIGPROC header differs"
     assert fr.data.shape == fg.data.shape
     if ocfg.nbit == -32:
+        # float output x = (P + offset) * scale: the power bound times the (product, channel) scale actually applied
+        # (slope of x against P over the series; 1.5x slack where the pair changes per interval), plus fp32 rounding of x
         ref = fr.data.astype(np.float64)
-        np.testing.assert_allclose(fg.data, ref, rtol=0, atol=POWER_RTOL * 50 * max(1.0, np.abs(ref).max()))
+        p = ocfg.result["power"]                                            # [nif][C][nt]
+        x = ocfg.result["rescaled"]
+        tot = p[:1] if p.shape[0] == 1 or ocfg.pol_mode == 5 else p[0:1] + p[1:2]
+        chan_mean = np.abs(tot).mean(axis=2)                                # [1][C]
+        sp = p.std(axis=2)
+        slope = np.where(sp > 0, x.std(axis=2) / np.where(sp > 0, sp, 1.0), 1.0)   # [nif][C]
+        slack = 1.0 if (ocfg.rescale_constant or ocfg.rescale_interval_s <= 0) else 1.5
+        tol = slack * POWER_RTOL * chan_mean * slope                        # [nif][C]
+        if ocfg.bw_mhz > 0:
+            tol = tol[:, ::-1]
+        err = np.abs(fg.data.astype(np.float64) - ref)
+        bound = tol[None, :, :] + 2.5e-7 * np.abs(ref)
+        assert np.all(err <= bound), f"float output off by {(err / bound).max():.2f} x the stated bound"
         return 0
     d = fg.data.astype(np.int64) - fr.data.astype(np.int64)
     bad = np.nonzero(d)

@@ -23,6 +23,11 @@ CASES = [
     (16.0, 32, 0.05, dict(pol=1, freq_res=64, interval=0.004, const=0)),  # no -c: per-interval rescale
     (16.0, 32, 0.05, dict(freq_res=64, interval=0.004, const=1, maxb=3)),
     (32.0, 1024, 0.14, {}),                                  # BASELINE config 2 shape, 2 blocks (fast K1+K2, M=8)
+    (32.0, 1024, 0.14, dict(flags=1 << 24)),                 # frbch_k1_split (bin-parity halves, 16 waves per CU) instead of the wave K1
+    (-32.0, 1024, 0.14, dict(flags=(1 << 24) | (1 << 21), pol=4)),   # ... storing the slab layout
+    (32.0, 1024, 0.27, dict(flags=1 << 24, maxb=3)),         # ... over uneven batches (3 + 1 blocks)
+    (32.0, 1024, 0.27, dict(maxb=3)),
+    (32.0, 1024, 0.14, dict(flags=1 << 23)),                 # no corner-turned copy: the wave K1 gathers from the frames
     (32.0, 1024, 0.14, dict(flags=1 << 21)),                 # slab layout of the spill instead of the tile-major one
     (-32.0, 1024, 0.14, dict(flags=1 << 21, pol=4, tscr=2)),
     (32.0, 1024, 0.14, dict(flags=3)),                       # same through the generic kernels
@@ -110,7 +115,7 @@ def test_power_tap_matches_oracle(hip_lib):
         pw = DeviceBuffer(nblocks * info.rows_per_block * 4 * nchan * 4)
         c.power_device(d_raw.ptr.value, nfr, 8032, 32, 0, nblocks, pw.ptr.value, pw.nbytes)
         got = pw.to_numpy(np.float32).reshape(want.shape).astype(np.float64)
-    scale = ocfg.result["power"][0].mean()
+    scale = (ocfg.result["power"][0] + ocfg.result["power"][1]).mean()           # mean total power PP + QQ
     err = np.abs(got - want).max() / scale
-    print("max |P - P_oracle| / mean(P) =", err)
+    print("max |P - P_oracle| / mean(PP+QQ) =", err)
     assert err <= pu.POWER_RTOL, err
