@@ -251,6 +251,8 @@ def host_inclusive(args, torch, dist, ch, cfg_kwargs, frames, nfr, rank, world, 
         with ch.Channeliser(ch.new_config(**cfg_kwargs)) as c:
             for i in range(args.host_runs + 1):          # first pass untimed: pinned buffers, page cache, clocks
                 c.reset()
+                if os.path.exists(fil):
+                    os.remove(fil)        # what run_digifil does with --force before the call (process_vdif.py:146-149)
                 if dist is not None:
                     dist.barrier()
                 t0 = time.perf_counter()

@@ -51,6 +51,12 @@ class FrbchInfo(C.Structure):
     ]
 
 
+class FrbchFilDesc(C.Structure):
+    _fields_ = [("size", C.c_uint32), ("nchan", C.c_uint32), ("nifs", C.c_uint32), ("nbits", C.c_int32),
+                ("product", C.c_uint32), ("reserved", C.c_uint32),
+                ("fch1_mhz", C.c_double), ("foff_mhz", C.c_double), ("tsamp_s", C.c_double), ("tstart_mjd", C.c_double)]
+
+
 class _KTiming(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double),
                 ("algorithmic_bytes", C.c_double)]
@@ -89,6 +95,16 @@ SYMBOLS = {
                                       _P, C.c_size_t, _P]),
     "frbch_get_rescale": (C.c_int, [_P, _P, _P]),
     "frbch_set_rescale": (C.c_int, [_P, _P, _P]),
+    "frbch_dedisperse_nout": (C.c_long, [C.POINTER(FrbchFilDesc), C.c_uint64, _P, C.c_uint32]),
+    "frbch_dedisperse_host": (C.c_int, [C.POINTER(FrbchFilDesc), _P, C.c_uint64, _P, C.c_uint32, C.c_uint32, C.c_double,
+                                        C.c_int, _P, C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]),
+    "frbch_dedisperse_device": (C.c_int, [C.POINTER(FrbchFilDesc), _P, C.c_uint64, _P, C.c_uint32, C.c_uint32, C.c_double,
+                                          C.c_int, _P, C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]),
+    "frbch_fold_nsub": (C.c_long, [C.POINTER(FrbchFilDesc), C.c_uint64, C.c_double]),
+    "frbch_fold_host": (C.c_int, [C.POINTER(FrbchFilDesc), _P, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double,
+                                  C.c_uint32, C.c_uint32, C.c_double, C.c_int, _P, _P, C.c_uint32, C.c_char_p, C.c_size_t]),
+    "frbch_fold_device": (C.c_int, [C.POINTER(FrbchFilDesc), _P, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double,
+                                    C.c_uint32, C.c_uint32, C.c_double, C.c_int, _P, _P, C.c_uint32, C.c_char_p, C.c_size_t]),
     "frbch_set_profiling": (C.c_int, [_P, C.c_int]),
     "frbch_timing_reset": (C.c_int, [_P]),
     "frbch_get_timing": (C.c_int, [_P, C.POINTER(FrbchTiming)]),

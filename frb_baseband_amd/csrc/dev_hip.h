@@ -37,6 +37,12 @@ typedef float frbch_nf4 __attribute__((ext_vector_type(4)));
   } while (0)
 #define STORE_U32_STREAM(ptr, val) __builtin_nontemporal_store((uint32_t)(val), (uint32_t*)(ptr))
 
+// atomics of the post-filterbank kernels (kernels_post.inc); double-precision phase arithmetic must not be contracted
+#define ATOMIC_ADD_U64(ptr, v) atomicAdd((unsigned long long*)(ptr), (unsigned long long)(v))
+#define ATOMIC_ADD_U32(ptr, v) atomicAdd((unsigned int*)(ptr), (unsigned int)(v))
+#define ATOMIC_ADD_F64(ptr, v) atomicAdd((double*)(ptr), (double)(v))
+#define POST_NO_CONTRACT _Pragma("clang fp contract(off)")
+
 typedef hipStream_t dev_stream_t;
 typedef hipEvent_t dev_event_t;
 

@@ -12,7 +12,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -98,6 +100,10 @@ struct frbch_handle {
   bool stg_ready = false;          // ... valid for the launch in progress
   std::vector<uint8_t> outq;
   size_t outq_pos = 0;
+  // whole-file paths: pinned host rings, kept for the life of the handle (pinning costs ~0.5 ms per MB)
+  uint8_t* pin_in[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  uint8_t* pin_out[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t pin_in_cap = 0, pin_out_cap = 0;
   // frbch_run_scan: rows go into this IF's columns of a pitched device buffer shared by the IFs of the scan
   uint8_t* sink = nullptr;         // first byte of this IF's columns in line 0
   size_t sink_line_pitch = 0;      // bytes per (row, product) line of the shared buffer
@@ -1137,6 +1143,7 @@ extern "C" void frbch_close(frbch_handle* h) {
   dev_free(h->spill2); dev_free(h->chirp); dev_free(h->ptmp);
   dev_free(h->offset); dev_free(h->scale); dev_free(h->powbuf); dev_free(h->partial);
   dev_free(h->d_frames); dev_free(h->d_out); dev_free(h->stg);
+  for (int i = 0; i < 8; ++i) { dev_host_free(h->pin_in[i]); dev_host_free(h->pin_out[i]); }
   if (h->stream) dev_stream_destroy(h->stream);
   delete h;
 }
@@ -1565,19 +1572,49 @@ namespace {
 // buffers while the GPU works on the current one, rows come back through two pinned buffers that a writer thread
 // drains into the output (strictly sequential writes: the target may be a FIFO).  No copy through `carry` / `outq`.
 // Returns FRBCH_OK, an error, or 1 = "not applicable, use the generic stream path" (nothing consumed).
-struct PipeQueue {          // two-slot hand-off between two threads
+constexpr int kMaxSlots = 8;
+struct PipeQueue {          // ring of pinned slots between the engine thread and the I/O threads
   std::mutex m;
   std::condition_variable cv;
-  int ready[2] = {0, 0};    // slot state: 0 free, 1 filled
-  size_t nbytes[2] = {0, 0};
+  int ready[kMaxSlots] = {0};    // slot state: 0 free, 1 filled
+  size_t nbytes[kMaxSlots] = {0};
+  uint64_t offs[kMaxSlots] = {0};   // output: file offset of the slot's bytes (regular files: positional writes)
   bool stop = false;
   int error = 0;
 };
+bool pwrite_all(int fd, const uint8_t* p, size_t n, uint64_t off) {
+  while (n) {
+    const ssize_t w = pwrite(fd, p, n, (off_t)off);
+    if (w < 0) {
+      if (errno == EINTR) continue;
+      return false;
+    }
+    p += w;
+    n -= (size_t)w;
+    off += (uint64_t)w;
+  }
+  return true;
+}
 
 // hs: one handle (rows come out of its own staging area) or the IFs of a scan (d_rows != null: every handle's rows go
 // into its columns of the pitched buffer d_rows through its sink, rows every IF has delivered are written).
+#ifdef FRBCH_EXPERIMENTS
+struct PhaseClock {   // FRBCH_TIMING=1: wall-clock phases of a whole-file call on stderr
+  bool on = getenv("FRBCH_TIMING") != nullptr;
+  double t0 = now();
+  static double now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+  void mark(const char* what) { if (on) { const double t = now(); fprintf(stderr, "[frbch timing] %-28s %8.2f ms\n", what, (t - t0) * 1e3); t0 = t; } }
+};
+#define PHASE_MARK(pc, what) (pc).mark(what)
+#else
+struct PhaseClock {};
+#define PHASE_MARK(pc, what) ((void)0)
+#endif
+
 int run_pipelined(frbch_handle* const* hs, uint32_t nif, const int* in_fds, int out_fd, uint8_t* d_rows, size_t row_pitch) {
   frbch_handle* h0 = hs[0];
+  PhaseClock pc;
+  (void)pc;
   const bool scan = d_rows != nullptr;
   struct Batch { uint64_t nb, f0, nfr, pay_off; };
   std::vector<std::vector<Batch>> batches(nif);
@@ -1615,20 +1652,37 @@ int run_pipelined(frbch_handle* const* hs, uint32_t nif, const int* in_fds, int 
   const Plan& pl0 = h0->pl;
   int rc = FRBCH_OK;
 
-  // pinned staging is expensive to allocate (~0.5 ms per MB): small pieces, two of each
-  const size_t in_cap = (size_t)std::max<uint64_t>(fbmax, ((16u << 20) / fbmax) * fbmax);
-  const size_t out_cap = std::max<size_t>(16u << 20, scan ? row_pitch : 0);
-  uint8_t* inbuf[2] = {nullptr, nullptr};
-  uint8_t* outbuf[2] = {nullptr, nullptr};
-  auto release = [&]() {
-    for (int i = 0; i < 2; ++i) { dev_host_free(inbuf[i]); dev_host_free(outbuf[i]); }
-  };
-  for (int i = 0; i < 2; ++i)
-    if (dev_host_alloc((void**)&inbuf[i], in_cap) != 0 || dev_host_alloc((void**)&outbuf[i], out_cap) != 0) {
-      release();
-      return fail(h0, FRBCH_E_NOMEM, "pinned staging buffers");
+  PHASE_MARK(pc, "stream_begin (allocations)");
+  // Pinned rings (kept in the first handle: pinning costs ~0.5 ms per MB).  Page-cache / tmpfs reads run at ~3 GB/s per
+  // thread, far below the PCIe link, and scale with threads: each input slot has its own reader thread (pread).
+  // Writes into ONE file do not scale (the kernel serialises them per inode; positional writes from four threads and
+  // parallel copies into a shared mapping were both measured slower than one stream, tools_runfile_timing.py): one
+  // writer, strictly sequential write() calls -- which is also what a FIFO target needs (base2fil.sh:348-349).
+  const size_t slot_bytes = 16u << 20;
+  const size_t in_cap = (size_t)std::max<uint64_t>(fbmax, (slot_bytes / fbmax) * fbmax);
+  const size_t out_cap = std::max<size_t>(slot_bytes, scan ? row_pitch : 0);
+  uint64_t in_total = 0;
+  for (uint32_t i = 0; i < nif; ++i)
+    for (const Batch& b : batches[i]) in_total += b.nfr * hs[i]->v0.frame_bytes;
+  const int NR = (int)std::min<uint64_t>(kMaxSlots, std::max<uint64_t>(2, (in_total + in_cap - 1) / in_cap));
+  const int NSO = NR;                                   // output slots
+  const int NWR = 1;                                    // writer threads
+  if (h0->pin_in_cap < in_cap || h0->pin_out_cap < out_cap) {
+    for (int i = 0; i < kMaxSlots; ++i) {
+      dev_host_free(h0->pin_in[i]); h0->pin_in[i] = nullptr;
+      dev_host_free(h0->pin_out[i]); h0->pin_out[i] = nullptr;
     }
+    h0->pin_in_cap = in_cap;
+    h0->pin_out_cap = out_cap;
+  }
+  uint8_t** inbuf = h0->pin_in;
+  uint8_t** outbuf = h0->pin_out;
+  for (int i = 0; i < NR; ++i)
+    if ((!inbuf[i] && dev_host_alloc((void**)&inbuf[i], in_cap) != 0) || (!outbuf[i] && dev_host_alloc((void**)&outbuf[i], out_cap) != 0))
+      return fail(h0, FRBCH_E_NOMEM, "pinned staging buffers");
+  auto release = [&]() {};   // (the rings stay with the handle until frbch_close)
 
+  PHASE_MARK(pc, "pinned rings");
   // every batch's frames travel in pieces of whole frames that fit a pinned buffer; batch rounds go IF by IF
   struct Piece { uint32_t ifx; size_t batch; uint64_t f0, nfr; size_t dst_off; bool ends_batch, ends_round; };
   std::vector<Piece> pieces;
@@ -1647,52 +1701,60 @@ int run_pipelined(frbch_handle* const* hs, uint32_t nif, const int* in_fds, int 
   }
 
   PipeQueue qin, qout;
-  std::thread reader([&]() {
-    for (size_t i = 0; i < pieces.size(); ++i) {
-      const int slot = (int)(i & 1);
-      {
-        std::unique_lock<std::mutex> lk(qin.m);
-        qin.cv.wait(lk, [&] { return qin.ready[slot] == 0 || qin.stop; });
-        if (qin.stop) return;
+  std::vector<std::thread> readers, writers;
+  for (int r = 0; r < NR; ++r)
+    readers.emplace_back([&, r]() {                // reader r owns input slot r: pieces r, r + NR, ...
+      for (size_t i = (size_t)r; i < pieces.size(); i += (size_t)NR) {
+        {
+          std::unique_lock<std::mutex> lk(qin.m);
+          qin.cv.wait(lk, [&] { return qin.ready[r] == 0 || qin.stop; });
+          if (qin.stop) return;
+        }
+        const uint64_t fb = hs[pieces[i].ifx]->v0.frame_bytes;
+        const size_t want = (size_t)(pieces[i].nfr * fb);
+        size_t got = 0;
+        int err = 0;
+        while (got < want) {
+          const ssize_t n = pread(in_fds[pieces[i].ifx], inbuf[r] + got, want - got, (off_t)(pieces[i].f0 * fb + got));
+          if (n < 0 && errno == EINTR) continue;
+          if (n <= 0) { err = n < 0 ? errno : EIO; break; }
+          got += (size_t)n;
+        }
+        std::lock_guard<std::mutex> lk(qin.m);
+        if (got != want) qin.error = err ? err : EIO;
+        qin.nbytes[r] = got;
+        qin.ready[r] = 1;
+        qin.cv.notify_all();
+        if (qin.error) return;
       }
-      const uint64_t fb = hs[pieces[i].ifx]->v0.frame_bytes;
-      const size_t want = (size_t)(pieces[i].nfr * fb);
-      size_t got = 0;
-      while (got < want) {
-        const ssize_t n = pread(in_fds[pieces[i].ifx], inbuf[slot] + got, want - got, (off_t)(pieces[i].f0 * fb + got));
-        if (n < 0 && errno == EINTR) continue;
-        if (n <= 0) break;
-        got += (size_t)n;
+    });
+  for (int w = 0; w < NWR; ++w)
+    writers.emplace_back([&, w]() {                // one writer, slots in order
+      for (size_t i = (size_t)w;; i += (size_t)NWR) {
+        const int slot = (int)(i % (size_t)NSO);
+        size_t n;
+        uint64_t off;
+        {
+          std::unique_lock<std::mutex> lk(qout.m);
+          qout.cv.wait(lk, [&] { return qout.ready[slot] == 1 || qout.stop; });
+          if (qout.ready[slot] != 1) return;       // stop and nothing pending
+          n = qout.nbytes[slot];
+          off = qout.offs[slot];
+        }
+        (void)off;
+        const bool ok = write_all(out_fd, outbuf[slot], n);
+        const int err = ok ? 0 : (errno ? errno : EIO);
+        std::lock_guard<std::mutex> lk(qout.m);
+        if (!ok) qout.error = err;
+        qout.ready[slot] = 0;
+        qout.cv.notify_all();
+        if (!ok) return;
       }
-      std::lock_guard<std::mutex> lk(qin.m);
-      if (got != want) qin.error = errno ? errno : EIO;
-      qin.nbytes[slot] = got;
-      qin.ready[slot] = 1;
-      qin.cv.notify_all();
-      if (qin.error) return;
-    }
-  });
-  std::thread writer([&]() {
-    for (size_t i = 0;; ++i) {
-      const int slot = (int)(i & 1);
-      size_t n;
-      {
-        std::unique_lock<std::mutex> lk(qout.m);
-        qout.cv.wait(lk, [&] { return qout.ready[slot] == 1 || qout.stop; });
-        if (qout.ready[slot] != 1) return;       // stop and nothing pending
-        n = qout.nbytes[slot];
-      }
-      const bool ok = write_all(out_fd, outbuf[slot], n);
-      std::lock_guard<std::mutex> lk(qout.m);
-      if (!ok) qout.error = errno ? errno : EIO;
-      qout.ready[slot] = 0;
-      qout.cv.notify_all();
-      if (!ok) return;
-    }
-  });
+    });
   size_t out_i = 0;                                // next output slot
+  uint64_t out_off = 0;                            // bytes handed to the writers so far = file offset of the next slot
   auto out_acquire = [&]() -> int {                // wait until the slot is free; returns slot or -1 on writer error
-    const int slot = (int)(out_i & 1);
+    const int slot = (int)(out_i % (size_t)NSO);
     std::unique_lock<std::mutex> lk(qout.m);
     qout.cv.wait(lk, [&] { return qout.ready[slot] == 0 || qout.error; });
     return qout.error ? -1 : slot;
@@ -1700,11 +1762,14 @@ int run_pipelined(frbch_handle* const* hs, uint32_t nif, const int* in_fds, int 
   auto out_submit = [&](int slot, size_t n) {
     std::lock_guard<std::mutex> lk(qout.m);
     qout.nbytes[slot] = n;
+    qout.offs[slot] = out_off;
+    out_off += n;
     qout.ready[slot] = 1;
     ++out_i;
     qout.cv.notify_all();
   };
-  // `total` bytes at device address `src` -> pinned buffers -> writer
+  // `total` bytes at device address `src` -> pinned slots -> writers.  The copy of slot k+1 is queued before the engine
+  // thread waits for slot k, so the link stays busy while a writer drains.
   auto emit_bytes = [&](const uint8_t* src, size_t total, dev_stream_t st) -> int {
     for (size_t off = 0; off < total;) {
       const size_t n = std::min(out_cap, total - off);
@@ -1757,7 +1822,7 @@ int run_pipelined(frbch_handle* const* hs, uint32_t nif, const int* in_fds, int 
   }
   std::vector<uint64_t> checked_upto(nif, 0);      // file frame index below which headers were checked
   for (size_t pi = 0; pi < pieces.size() && !rc; ++pi) {
-    const int slot = (int)(pi & 1);
+    const int slot = (int)(pi % (size_t)NR);
     const Piece& pc = pieces[pi];
     frbch_handle* h = hs[pc.ifx];
     const Plan& pl = h->pl;
@@ -1806,6 +1871,7 @@ int run_pipelined(frbch_handle* const* hs, uint32_t nif, const int* in_fds, int 
     }
     if (!rc && scan && pc.ends_round) rc = drain_scan(false);
   }
+  PHASE_MARK(pc, "input + transform");
   for (uint32_t i = 0; i < nif && !rc; ++i) {
     frbch_handle* h = hs[i];
     uint64_t rows = 0;
@@ -1814,18 +1880,24 @@ int run_pipelined(frbch_handle* const* hs, uint32_t nif, const int* in_fds, int 
     if (!rc && rows) rc = scan ? queue_rows(h, rows) : emit_bytes(h->d_out, (size_t)(rows * h->pl.row_bytes), h->stream);
   }
   if (!rc && scan) rc = drain_scan(true);
-  {   // stop the threads: the reader may be waiting for a slot, the writer for data
+  PHASE_MARK(pc, "flush + output");
+  {   // stop the threads: readers may be waiting for a slot, writers for data
     { std::lock_guard<std::mutex> lk(qin.m); qin.stop = true; qin.cv.notify_all(); }
-    reader.join();
-    {   // let the writer drain what is queued, then stop
+    for (auto& t : readers) t.join();
+    {   // let the writers drain what is queued, then stop
       std::unique_lock<std::mutex> lk(qout.m);
-      qout.cv.wait(lk, [&] { return (qout.ready[0] == 0 && qout.ready[1] == 0) || qout.error; });
+      qout.cv.wait(lk, [&] {
+        bool idle = true;
+        for (int i = 0; i < NSO; ++i) idle = idle && qout.ready[i] == 0;
+        return idle || qout.error;
+      });
       qout.stop = true;
       qout.cv.notify_all();
     }
-    writer.join();
+    for (auto& t : writers) t.join();
     if (!rc && qout.error) rc = fail(h0, FRBCH_E_IO, std::string("write: ") + strerror(qout.error));
   }
+  PHASE_MARK(pc, "writers drained");
   release();
   return rc;
 }
@@ -2037,3 +2109,5 @@ extern "C" int frbch_run_scan(frbch_handle* const* ifs, uint32_t nif, const char
   cleanup();
   return rc;
 }
+
+#include "frbch_post.inc"

@@ -239,8 +239,13 @@ def main(argv=None):
                                  keepBP=args.keepBP, backend=backend, device=device, iquv=iquv)
     if args.do_prepdata:
         dm1 = args.dm if args.dm is not None else psr_info(args.psrname)[2]
-        prepdata(filterbankfile, dm1, zerodm=args.nozerodm, clip=args.clip, dm2=args.dm2, dmstep=args.dmstep,
-                 ncpus=args.ncpus)
+        if os.environ.get("FRBCH_PREP", "presto") == "gpu":      # same options, dedispersed by libfrbch instead of PRESTO
+            from . import post
+            post.prepdata_gpu(filterbankfile, dm1, zerodm=args.nozerodm, clip=args.clip, dm2=args.dm2, dmstep=args.dmstep,
+                              ncpus=args.ncpus, device=int(device or 0))
+        else:
+            prepdata(filterbankfile, dm1, zerodm=args.nozerodm, clip=args.clip, dm2=args.dm2, dmstep=args.dmstep,
+                     ncpus=args.ncpus)
     return 0
 
 

@@ -211,6 +211,49 @@ int frbch_unpack_device(frbch_handle* h, const void* d_frames, size_t nframes, u
 int frbch_get_rescale(frbch_handle* h, float* offset, float* scale);
 int frbch_set_rescale(frbch_handle* h, const float* offset, const float* scale);
 
+/* ---- after the filterbank ------------------------------------------------
+ * The rows of a SIGPROC filterbank -- [t][nifs][nchan] samples of 8 or 16 bit (unsigned) or float32, as frbch_run_file /
+ * frbch_run_scan write them -- dedispersed incoherently or folded on the GPU.  The reference delegates both to external
+ * programs: PRESTO's prepdata / prepsubband (process_vdif.py:202-229: `-dm`, `-lodm -numdms -dmstep`, `-zerodm`,
+ * `-clip`, always `-nobary -noweights -noscales`) and `dspsr -E <par> -L 10 -A -d1 <IFall.fil>` (base2fil.sh:474).
+ * Neither program is in the reference tree: the conventions are this library's (oracle/post_oracle.py states them).
+ * `_host` variants take host pointers and move the data themselves; `_device` variants work on rows already in HBM. */
+typedef struct frbch_fil_desc {
+  uint32_t size;               /* = sizeof(frbch_fil_desc)                                                      */
+  uint32_t nchan, nifs;        /* SIGPROC nchans, nifs                                                           */
+  int32_t nbits;               /* 8, 16 (unsigned codes) or 32 (float32)                                         */
+  uint32_t product;            /* which of the nifs products is used (0 = PP+QQ of -d1, or I of IQUV)            */
+  uint32_t reserved;
+  double fch1_mhz, foff_mhz;   /* SIGPROC fch1 / foff (centre of channel 0, channel step; foff < 0 as written here) */
+  double tsamp_s, tstart_mjd;
+} frbch_fil_desc;
+
+/* Output samples per DM: nrows minus the largest delay of any requested DM (delay of channel c = DM / 2.41e-4 *
+ * (f_c^-2 - f_top^-2) s, rounded to samples as int(x + 0.5)).  < 0: bad arguments. */
+long frbch_dedisperse_nout(const frbch_fil_desc* fil, uint64_t nrows, const double* dms, uint32_t ndm);
+/* out[dm][t] = sum_c x[t + delay_c(dm)][c]  (float32), after the optional time-domain clip (`-clip <sigma>`: a time
+ * sample whose zero-DM sum lies more than clip_sigma sigma off the mean -- two rounds -- is replaced by the channel means
+ * of the unclipped samples) and the optional zero-DM filter (`-zerodm`: the mean over channels of every time sample is
+ * subtracted).  *nclipped receives the number of clipped time samples.  Integer rows: every sum is exact. */
+int frbch_dedisperse_host(const frbch_fil_desc* fil, const void* rows, uint64_t nrows, const double* dms, uint32_t ndm,
+                          uint32_t zerodm, double clip_sigma, int device, float* out, uint64_t nout,
+                          uint64_t* nclipped, char* err, size_t err_cap);
+int frbch_dedisperse_device(const frbch_fil_desc* fil, const void* d_rows, uint64_t nrows, const double* dms, uint32_t ndm,
+                            uint32_t zerodm, double clip_sigma, int device, float* d_out, uint64_t nout,
+                            uint64_t* nclipped, char* err, size_t err_cap);
+/* Sub-integrations of subint_s seconds (dspsr -L): ceil(nrows / round(subint_s / tsamp)). */
+long frbch_fold_nsub(const frbch_fil_desc* fil, uint64_t nrows, double subint_s);
+/* Phase fold with the spin of a .par file: turns(tau) = F0 tau + F1 tau^2 / 2, tau = (tstart - PEPOCH) + t tsamp
+ * [- delay_c(dm) when apply_delays: incoherent inter-channel dedispersion at fold time; 0 = what dspsr does with a
+ * filterbank: channels are folded as they arrive and the archive keeps DM for a later `dedisperse`].  Topocentric: no
+ * barycentric, binary or position terms.  profile[sub][bin][chan] = sum of the samples, hits[...] = their number. */
+int frbch_fold_host(const frbch_fil_desc* fil, const void* rows, uint64_t nrows, double f0_hz, double f1, double pepoch_mjd,
+                    double dm, uint32_t apply_delays, uint32_t nbin, double subint_s, int device, double* profile,
+                    uint32_t* hits, uint32_t nsub, char* err, size_t err_cap);
+int frbch_fold_device(const frbch_fil_desc* fil, const void* d_rows, uint64_t nrows, double f0_hz, double f1,
+                      double pepoch_mjd, double dm, uint32_t apply_delays, uint32_t nbin, double subint_s, int device,
+                      double* d_profile, uint32_t* d_hits, uint32_t nsub, char* err, size_t err_cap);
+
 /* ---- measurement -------------------------------------------------------------------------- */
 int frbch_set_profiling(frbch_handle* h, int enable);
 int frbch_timing_reset(frbch_handle* h);

@@ -23,6 +23,23 @@
 #define LOAD_F4_STREAM(dst, ptr) ((dst) = *(const f4*)(ptr))
 #define STORE_U32_STREAM(ptr, val) (*(uint32_t*)(ptr) = (uint32_t)(val))
 
+static inline void emu_atomic_add_u64(unsigned long long* p, unsigned long long v) {
+#pragma omp atomic
+  *p += v;
+}
+static inline void emu_atomic_add_u32(unsigned int* p, unsigned int v) {
+#pragma omp atomic
+  *p += v;
+}
+static inline void emu_atomic_add_f64(double* p, double v) {
+#pragma omp atomic
+  *p += v;
+}
+#define ATOMIC_ADD_U64(ptr, v) emu_atomic_add_u64((unsigned long long*)(ptr), (unsigned long long)(v))
+#define ATOMIC_ADD_U32(ptr, v) emu_atomic_add_u32((unsigned int*)(ptr), (unsigned int)(v))
+#define ATOMIC_ADD_F64(ptr, v) emu_atomic_add_f64((double*)(ptr), (double)(v))
+#define POST_NO_CONTRACT   /* built with -ffp-contract=off */
+
 typedef void* dev_stream_t;
 typedef int dev_event_t;
 
