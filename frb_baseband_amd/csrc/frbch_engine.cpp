@@ -89,7 +89,10 @@ struct frbch_handle {
   uint64_t skip_bytes = 0;      // payload bytes still to skip before the next block starts
   uint64_t blocks_budget = 0;   // blocks still allowed by -T
   std::vector<uint8_t> carry;   // whole + partial frames not yet consumed
-  uint64_t frames_seen = 0, frames_invalid = 0, frame_gaps = 0;
+  uint64_t frames_seen = 0, frames_invalid = 0, frame_gaps = 0, frames_filled = 0;
+  std::vector<uint8_t> carry_bad;  // per frame of `carry`: 1 = flagged invalid, or a filler inserted for a missing frame number
+  uint32_t* d_fbad = nullptr;      // bitmap of those flags for the frames of the launch in progress
+  size_t d_fbad_words = 0;
   uint64_t next_frame_index = 0;   // seconds*fps + frame_nr expected next
   size_t checked_bytes = 0;        // prefix of `carry` whose headers were already checked
   uint8_t* d_frames = nullptr;
@@ -786,12 +789,18 @@ int launch_front(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   const Plan& pl = h->pl;
   p.tile_major = 0;   // set by the K1 that writes that layout
   {
-    launch_k0_stage(h, p, nb, s);
+    const bool masked = p.fbad != nullptr;   // blocks that touch invalid / filler frames: the generic K1 zeroes those samples
+    if (!masked) launch_k0_stage(h, p, nb, s);
     const double bytes = (double)nb * ((double)pl.block_payload_bytes * p.frame_bytes / p.payload_bytes +
                                        (double)pl.n * 8.0 + (double)pl.c2 * 8.0);
     ProfScope ps(h, s, KID_K1, bytes);
     bool done = false;
-    if (!pl.coherent) done = launch_k1_fast(h, p, nb, s);
+    if (masked) {
+      if (pl.coherent && h->coh_order_m) {   // from here on the generic K1 / K3 and their bin order
+        const int rc = build_chirp(h, 0);
+        if (rc) return rc;
+      }
+    } else if (!pl.coherent) done = launch_k1_fast(h, p, nb, s);
     else if (h->coh_order_m) {
       done = launch_k1_fast(h, p, nb, s);
       if (!done) {   // a start offset the register kernel cannot gather: from here on the generic K1 / K3 and their bin order
@@ -957,16 +966,52 @@ int finalize_interval(frbch_handle* h, uint64_t stat_rows, uint8_t* d_out, size_
 bool fused_ok(const frbch_handle* h) { return h->scale_frozen; }
 
 // Transform `nblocks` blocks starting `payload_off` bytes into the payload stream of d_frames.
+int engine_feed_run(frbch_handle* h, const uint8_t* d_frames, uint32_t frame_bytes, uint32_t header_bytes,
+                    uint64_t payload_off, uint64_t nblocks, uint8_t* d_out, size_t cap, uint64_t* rows_written,
+                    dev_stream_t s, const uint32_t* d_fbad);
+
+// `h_bad` (optional): one flag per frame of d_frames, 1 = the frame is flagged invalid or is a filler for a missing frame
+// number; `d_fbad` the same as a bitmap on the device.  Blocks that touch such a frame go through the generic K1, which
+// reads their samples as 0; all other blocks take the fast kernels as before.
 int engine_feed(frbch_handle* h, const uint8_t* d_frames, uint32_t frame_bytes, uint32_t header_bytes,
                 uint64_t payload_off, uint64_t nblocks, uint8_t* d_out, size_t cap, uint64_t* rows_written,
-                dev_stream_t s) {
+                dev_stream_t s, const uint8_t* h_bad = nullptr, uint64_t nfr_bad = 0, const uint32_t* d_fbad = nullptr) {
   const Plan& pl = h->pl;
   *rows_written = 0;
+  bool any = false;
+  for (uint64_t f = 0; h_bad && f < nfr_bad && !any; ++f) any = h_bad[f] != 0;
+  if (!any) return engine_feed_run(h, d_frames, frame_bytes, header_bytes, payload_off, nblocks, d_out, cap, rows_written, s, nullptr);
+  const uint64_t pb = frame_bytes - header_bytes;
+  auto dirty = [&](uint64_t b) {
+    const uint64_t a0 = payload_off + b * pl.block_stride_bytes, a1 = a0 + pl.block_payload_bytes - 1;
+    for (uint64_t f = a0 / pb; f <= a1 / pb && f < nfr_bad; ++f)
+      if (h_bad[f]) return true;
+    return false;
+  };
+  for (uint64_t b0 = 0; b0 < nblocks;) {
+    const bool d0 = dirty(b0);
+    uint64_t b1 = b0 + 1;
+    while (b1 < nblocks && dirty(b1) == d0) ++b1;
+    const int rc = engine_feed_run(h, d_frames, frame_bytes, header_bytes, payload_off + b0 * pl.block_stride_bytes, b1 - b0, d_out, cap,
+                                   rows_written, s, d0 ? d_fbad : nullptr);
+    if (rc) return rc;
+    b0 = b1;
+  }
+  return FRBCH_OK;
+}
+
+// one run of blocks; *rows_written is the running row count of the call (rows land behind those already written)
+int engine_feed_run(frbch_handle* h, const uint8_t* d_frames, uint32_t frame_bytes, uint32_t header_bytes,
+                    uint64_t payload_off, uint64_t nblocks, uint8_t* d_out, size_t cap, uint64_t* rows_written,
+                    dev_stream_t s, const uint32_t* d_fbad) {
+  const Plan& pl = h->pl;
   const uint64_t nbatch = (nblocks + pl.maxb - 1) / pl.maxb;
   const uint64_t per = nbatch ? (nblocks + nbatch - 1) / nbatch : 0;      // equal batches: no short tail launch
   for (uint64_t b0 = 0; b0 < nblocks; b0 += per) {
     const uint32_t nb = (uint32_t)std::min<uint64_t>(per, nblocks - b0);
     KParams p = base_params(h);
+    p.fbad = d_fbad;
+    p.fbad_frame0 = 0;
     p.frames = d_frames;
     p.frame_bytes = frame_bytes;
     p.header_bytes = header_bytes;
@@ -1142,7 +1187,7 @@ extern "C" void frbch_close(frbch_handle* h) {
   dev_free(h->spill); dev_free(h->s_dc); dev_free(h->p0);
   dev_free(h->spill2); dev_free(h->chirp); dev_free(h->ptmp);
   dev_free(h->offset); dev_free(h->scale); dev_free(h->powbuf); dev_free(h->partial);
-  dev_free(h->d_frames); dev_free(h->d_out); dev_free(h->stg);
+  dev_free(h->d_frames); dev_free(h->d_out); dev_free(h->stg); dev_free(h->d_fbad);
   for (int i = 0; i < 8; ++i) { dev_host_free(h->pin_in[i]); dev_host_free(h->pin_out[i]); }
   if (h->stream) dev_stream_destroy(h->stream);
   delete h;
@@ -1172,6 +1217,7 @@ extern "C" int frbch_get_info(frbch_handle* h, frbch_info* info) {
   info->frames_seen = h->frames_seen;
   info->frames_invalid = h->frames_invalid;
   info->frame_gaps = h->frame_gaps;
+  info->frames_filled = h->frames_filled;
   info->block_stride_bytes = pl.block_stride_bytes;
   info->nfilt_pos = (uint32_t)pl.nfilt_pos;
   info->nfilt_neg = (uint32_t)pl.nfilt_neg;
@@ -1198,7 +1244,8 @@ extern "C" int frbch_reset(frbch_handle* h) {
   h->fused_valid = false;
   h->rows_out = h->blocks_done = 0;
   h->have_vdif = false;
-  h->frames_seen = h->frames_invalid = h->frame_gaps = 0;
+  h->frames_seen = h->frames_invalid = h->frame_gaps = h->frames_filled = 0;
+  h->carry_bad.clear();
   h->next_frame_index = 0;
   h->checked_bytes = 0;
   h->carry.clear();
@@ -1457,12 +1504,53 @@ int check_headers(frbch_handle* h) {
         v.log2_nchan != h->v0.log2_nchan)
       return fail(h, FRBCH_E_FORMAT, "VDIF frame header changes geometry mid-stream (frame " + std::to_string(h->frames_seen) + ")");
     const uint64_t idx = (uint64_t)v.seconds * fps + v.frame_nr;
-    if (h->frames_seen && idx != h->next_frame_index) h->frame_gaps++;
+    if (h->frames_seen && idx != h->next_frame_index) {
+      h->frame_gaps++;
+      if (idx > h->next_frame_index) {   // frames are missing: keep the stream contiguous in time with zero-valued fillers
+        const uint64_t nfill = idx - h->next_frame_index;
+        if (nfill > 16 * fps) return fail(h, FRBCH_E_FORMAT, "VDIF frame numbers jump forward by more than 16 s (frame " + std::to_string(h->frames_seen) + ")");
+        std::vector<uint8_t> filler((size_t)(nfill * fb), 0);
+        for (uint64_t k = 0; k < nfill; ++k) {
+          memcpy(filler.data() + k * fb, h->carry.data() + h->checked_bytes, h->v0.header_bytes());
+          filler[k * fb + 3] |= 0x80;      // invalid flag (word 0, bit 31)
+        }
+        h->carry.insert(h->carry.begin() + (long)h->checked_bytes, filler.begin(), filler.end());
+        h->carry_bad.resize(h->checked_bytes / fb, 0);
+        h->carry_bad.insert(h->carry_bad.end(), (size_t)nfill, 1);
+        h->frames_filled += nfill;
+        h->checked_bytes += nfill * fb;
+      }
+      // (a backward jump -- duplicate or re-ordered frames -- is counted and the data used as they come: -cont)
+    }
     h->next_frame_index = idx + 1;
     if (v.invalid) h->frames_invalid++;
+    h->carry_bad.resize(h->checked_bytes / fb, 0);
+    h->carry_bad.push_back(v.invalid ? 1 : 0);
     h->frames_seen++;
     h->checked_bytes += fb;
   }
+  return FRBCH_OK;
+}
+
+// bitmap of the bad-frame flags of `nfr` frames starting at flags[0], on the device (null when none is set)
+int upload_bad_frames(frbch_handle* h, const uint8_t* flags, uint64_t nfr, const uint32_t** d_out) {
+  *d_out = nullptr;
+  bool any = false;
+  for (uint64_t f = 0; f < nfr && !any; ++f) any = flags[f] != 0;
+  if (!any) return FRBCH_OK;
+  const size_t words = (size_t)((nfr + 31) / 32);
+  if (h->d_fbad_words < words) {
+    dev_free(h->d_fbad);
+    h->d_fbad = nullptr;
+    CHECK_DEV(h, dev_malloc((void**)&h->d_fbad, words * sizeof(uint32_t)), "hipMalloc(frame flags)");
+    h->d_fbad_words = words;
+  }
+  std::vector<uint32_t> bits(words, 0u);
+  for (uint64_t f = 0; f < nfr; ++f)
+    if (flags[f]) bits[f >> 5] |= 1u << (f & 31);
+  CHECK_DEV(h, dev_h2d(h->d_fbad, bits.data(), words * sizeof(uint32_t), h->stream), "upload frame flags");
+  CHECK_DEV(h, dev_sync(h->stream), "sync");     // `bits` is released on return
+  *d_out = h->d_fbad;
   return FRBCH_OK;
 }
 
@@ -1488,8 +1576,12 @@ int process_carry(frbch_handle* h) {
     const uint8_t* src = h->carry.data() + consumed_frames * fb;
     CHECK_DEV(h, dev_h2d(h->d_frames, src, need_frames * fb, h->stream), "upload frames");
     uint64_t rows = 0;
-    int rc = engine_feed(h, h->d_frames, (uint32_t)fb, (uint32_t)hb, h->skip_bytes, nb, h->d_out, h->d_out_cap,
-                         &rows, h->stream);
+    const uint8_t* bad = h->carry_bad.size() >= consumed_frames + need_frames ? h->carry_bad.data() + consumed_frames : nullptr;
+    const uint32_t* d_bad = nullptr;
+    int rc = bad ? upload_bad_frames(h, bad, need_frames, &d_bad) : FRBCH_OK;
+    if (rc) return rc;
+    rc = engine_feed(h, h->d_frames, (uint32_t)fb, (uint32_t)hb, h->skip_bytes, nb, h->d_out, h->d_out_cap,
+                     &rows, h->stream, d_bad ? bad : nullptr, need_frames, d_bad);
     if (rc) return rc;
     rc = queue_rows(h, rows);  // also synchronises, so `src` may be released
     if (rc) return rc;
@@ -1498,10 +1590,12 @@ int process_carry(frbch_handle* h) {
     h->skip_bytes += nb * pl.block_stride_bytes;
   }
   if (consumed_frames) {
+    h->carry_bad.erase(h->carry_bad.begin(), h->carry_bad.begin() + (long)std::min<size_t>(consumed_frames, h->carry_bad.size()));
     h->carry.erase(h->carry.begin(), h->carry.begin() + consumed_frames * fb);
     h->checked_bytes = h->checked_bytes > consumed_frames * fb ? h->checked_bytes - consumed_frames * fb : 0;
   }
   if (h->blocks_budget == 0) {  // -T reached: ignore the rest
+    h->carry_bad.clear();
     h->carry.clear();
     h->checked_bytes = 0;
   }
@@ -1598,6 +1692,24 @@ bool pwrite_all(int fd, const uint8_t* p, size_t n, uint64_t off) {
 
 // hs: one handle (rows come out of its own staging area) or the IFs of a scan (d_rows != null: every handle's rows go
 // into its columns of the pitched buffer d_rows through its sink, rows every IF has delivered are written).
+// The whole-file fast path addresses frames by their position in the file: it needs a file whose frame numbers run without
+// a jump.  First and last header tell (seconds * fps + frame number must advance by exactly the frame count); a file
+// with missing frames takes the stream path, which fills the gaps (check_headers).
+bool vdif_file_contiguous(int fd, const frbch_config& cfg) {
+  struct stat st;
+  uint8_t a[16], b[16];
+  if (fstat(fd, &st) != 0 || st.st_size < 32 || pread(fd, a, 16, 0) != 16) return true;   // (let the caller report it)
+  VdifInfo v0, v1;
+  if (!parse_vdif_header(a, &v0) || v0.frame_bytes == 0) return true;
+  const uint64_t nfile = (uint64_t)st.st_size / v0.frame_bytes;
+  if (nfile < 2 || pread(fd, b, 16, (off_t)((nfile - 1) * v0.frame_bytes)) != 16) return true;
+  parse_vdif_header(b, &v1);
+  const double fps_d = 2.0e6 * fabs(cfg.bw_mhz) * 2.0 * v0.bits_per_sample / 8.0 / (double)v0.payload_bytes();
+  const uint64_t fps = (uint64_t)llround(fps_d);
+  const uint64_t i0 = (uint64_t)v0.seconds * fps + v0.frame_nr, i1 = (uint64_t)v1.seconds * fps + v1.frame_nr;
+  return i1 - i0 == nfile - 1;
+}
+
 #ifdef FRBCH_EXPERIMENTS
 struct PhaseClock {   // FRBCH_TIMING=1: wall-clock phases of a whole-file call on stderr
   bool on = getenv("FRBCH_TIMING") != nullptr;
@@ -1821,6 +1933,12 @@ int run_pipelined(frbch_handle* const* hs, uint32_t nif, const int* in_fds, int 
     }
   }
   std::vector<uint64_t> checked_upto(nif, 0);      // file frame index below which headers were checked
+  std::vector<std::vector<uint8_t>> bad_all(nif);  // per IF and file frame: 1 = flagged invalid (its samples read as 0)
+  for (uint32_t i = 0; i < nif; ++i) {
+    uint64_t last = 0;
+    for (const Batch& b : batches[i]) last = std::max(last, b.f0 + b.nfr);
+    bad_all[i].assign((size_t)last, 0);
+  }
   for (size_t pi = 0; pi < pieces.size() && !rc; ++pi) {
     const int slot = (int)(pi % (size_t)NR);
     const Piece& pc = pieces[pi];
@@ -1846,7 +1964,10 @@ int run_pipelined(frbch_handle* const* hs, uint32_t nif, const int* in_fds, int 
       const uint64_t idx = (uint64_t)v.seconds * fps + v.frame_nr;
       if (h->frames_seen && idx != h->next_frame_index) h->frame_gaps++;
       h->next_frame_index = idx + 1;
-      if (v.invalid) h->frames_invalid++;
+      if (v.invalid) {
+        h->frames_invalid++;
+        if (f < bad_all[pc.ifx].size()) bad_all[pc.ifx][(size_t)f] = 1;
+      }
       h->frames_seen++;
     }
     checked_upto[pc.ifx] = std::max(checked_upto[pc.ifx], pc.f0 + pc.nfr);
@@ -1863,7 +1984,11 @@ int run_pipelined(frbch_handle* const* hs, uint32_t nif, const int* in_fds, int 
     if (pc.ends_batch) {
       const Batch& b = batches[pc.ifx][pc.batch];
       uint64_t rows = 0;
-      rc = engine_feed(h, h->d_frames, (uint32_t)fb, (uint32_t)hb, b.pay_off, b.nb, h->d_out, h->d_out_cap, &rows, h->stream);
+      const uint8_t* bad = bad_all[pc.ifx].data() + b.f0;
+      const uint32_t* d_bad = nullptr;
+      rc = upload_bad_frames(h, bad, b.nfr, &d_bad);
+      if (!rc) rc = engine_feed(h, h->d_frames, (uint32_t)fb, (uint32_t)hb, b.pay_off, b.nb, h->d_out, h->d_out_cap, &rows, h->stream,
+                                d_bad ? bad : nullptr, b.nfr, d_bad);
       if (rc && h != h0) fail(h0, rc, std::string("IF ") + std::to_string(pc.ifx) + ": " + h->err);
       if (!rc && rows) rc = scan ? queue_rows(h, rows) : emit_bytes(h->d_out, (size_t)(rows * pl.row_bytes), h->stream);
       h->blocks_budget -= std::min<uint64_t>(h->blocks_budget, b.nb);
@@ -1916,7 +2041,7 @@ extern "C" int frbch_run_file(frbch_handle* h, const char* vdif_path, const char
     const int in_fd = open(vdif_path, O_RDONLY);
     if (in_fd < 0) return fail(h, FRBCH_E_IO, std::string("cannot open ") + vdif_path + ": " + strerror(errno));
     struct stat st;
-    if (fstat(in_fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= 32 && !h->have_vdif) {
+    if (fstat(in_fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= 32 && !h->have_vdif && vdif_file_contiguous(in_fd, h->cfg)) {
       // INSTALL.md:32-35: no O_EXCL, so that a pre-made FIFO (base2fil.sh:348-349) can be the target
       const int out_fd = open(out_fil, O_WRONLY | O_CREAT | O_TRUNC, 0644);
       if (out_fd < 0) {
@@ -2030,7 +2155,7 @@ extern "C" int frbch_run_scan(frbch_handle* const* ifs, uint32_t nif, const char
     for (uint32_t i = 0; i < nif; ++i) {
       fds[i] = open(vdif_paths[i], O_RDONLY);
       struct stat st;
-      if (fds[i] < 0 || fstat(fds[i], &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 32) regular = false;
+      if (fds[i] < 0 || fstat(fds[i], &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 32 || !vdif_file_contiguous(fds[i], ifs[i]->cfg)) regular = false;
     }
     if (regular) {
       rc = run_pipelined(ifs, nif, fds.data(), fd, d_rows, row_pitch);

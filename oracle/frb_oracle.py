@@ -128,6 +128,40 @@ def strip_frames(raw: np.ndarray, frame_bytes: int, header_bytes: int) -> np.nda
     return raw[: nfr * frame_bytes].reshape(nfr, frame_bytes)[:, header_bytes:].reshape(-1)
 
 
+def assemble_stream(raw: np.ndarray, rate: float):
+    """Frames as they come -> (payload bytes of a stream that is contiguous in time, bad[frame] flags, counters).
+
+    The reference passes `-cont` (process_vdif.py:157,160: treat the input as contiguous) and the tools around it read
+    the VDIF invalid flag and frame numbers (extract_baseband_chunk.py:56-69).  Convention of this build (DSPSR absent):
+    a frame whose invalid bit is set contributes ZERO voltages (the mean of the level table); a forward jump of the
+    frame number (seconds * fps + frame_nr) is filled with as many zero frames, so that later samples keep their time;
+    a backward jump is only counted."""
+    h0 = parse_vdif_header(raw[:32].tobytes())
+    fb, hb = h0.frame_bytes, h0.header_bytes
+    nfr = raw.size // fb
+    frames = raw[: nfr * fb].reshape(nfr, fb)
+    w = frames[:, :8].copy().view("<u4")                       # words 0, 1 of every header
+    invalid = ((w[:, 0] >> 31) & 1).astype(bool)
+    fps = int(round(rate * 2 * h0.bits_per_sample / 8 / h0.payload_bytes))
+    idx = (w[:, 0] & 0x3FFFFFFF).astype(np.int64) * fps + (w[:, 1] & 0xFFFFFF).astype(np.int64)
+    pieces, bad = [], []
+    gaps = filled = 0
+    nxt = None
+    for f in range(nfr):
+        if nxt is not None and idx[f] != nxt:
+            gaps += 1
+            if idx[f] > nxt:
+                nfill = int(idx[f] - nxt)
+                pieces.append(np.zeros(nfill * (fb - hb), np.uint8))
+                bad += [True] * nfill
+                filled += nfill
+        nxt = idx[f] + 1
+        pieces.append(frames[f, hb:])
+        bad.append(bool(invalid[f]))
+    payload = np.concatenate(pieces) if pieces else np.zeros(0, np.uint8)
+    return payload, np.array(bad, dtype=bool), dict(gaps=gaps, filled=filled, invalid=int(invalid.sum()))
+
+
 # --------------------------------------------------------------------------------------------
 # 2-bit unpack (A4): byte -> 4 floats
 # --------------------------------------------------------------------------------------------
@@ -462,8 +496,9 @@ def detected_power(raw_frames: np.ndarray, cfg: Config):
     Applies -S / -T (whole seconds counted in samples), drops the partial last block.
     """
     hdr = parse_vdif_header(raw_frames[:32].tobytes())
-    payload = strip_frames(raw_frames, hdr.frame_bytes, hdr.header_bytes)
     rate = 2.0e6 * abs(cfg.bw_mhz)                    # real samples / s / pol
+    payload, bad_frames, counters = assemble_stream(raw_frames, rate)
+    cfg.result["frame_counters"] = counters
     c = cfg.nchan
     r = cfg.freq_res or freq_res_for(c)
     pos = neg = 0
@@ -481,7 +516,13 @@ def detected_power(raw_frames: np.ndarray, cfg: Config):
     nwant = int(round(cfg.total_s * rate))
     nsamp = max(0, min(navail, nwant))
     nblocks = (nsamp - n) // hop + 1 if nsamp >= n else 0
-    x = unpack(payload[s0 // spb: s0 // spb + ((nblocks - 1) * hop + n) // spb if nblocks else s0 // spb], bits, cfg.levels)
+    b_lo = s0 // spb
+    b_hi = b_lo + ((nblocks - 1) * hop + n) // spb if nblocks else b_lo
+    x = unpack(payload[b_lo:b_hi], bits, cfg.levels)
+    if bad_frames.any() and b_hi > b_lo:              # invalid / filler frames: zero voltages
+        pbytes = hdr.payload_bytes
+        byte_bad = np.repeat(bad_frames, pbytes)[b_lo:b_hi]
+        x[:, np.repeat(byte_bad, spb)] = 0.0
     out = []
     for b in range(nblocks):
         xb = x[:, b * hop: b * hop + n]

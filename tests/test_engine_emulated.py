@@ -207,22 +207,51 @@ def test_device_entry_points_and_power_tap(emu_lib):
 
 
 def test_frame_header_checks(emu_lib):
-    """invalid flags and frame-number jumps are counted and, as -cont prescribes, used as contiguous data;
-    a header whose geometry changes mid-stream is an error."""
-    raw = synth.make_vdif(0.01, bw_mhz=16.0, nchan=32).copy()
-    cfg = pu.lib_cfg(emu_lib, 16.0, 32, 0.01, freq_res=64)
+    """invalid frames read as zero voltages, missing frame numbers are filled with zero frames (the stream stays
+    contiguous in time: -cont, process_vdif.py:157), both are counted; a header whose geometry changes mid-stream is an
+    error."""
+    raw = synth.make_vdif(0.012, bw_mhz=16.0, nchan=32).copy()
+    cfg = pu.lib_cfg(emu_lib, 16.0, 32, 0.012, freq_res=64)
     with ch.Channeliser(cfg, emu_lib) as c:
         clean = c.channelise_bytes(raw)
         assert c.get_info().frames_seen == raw.size // 8032 and c.get_info().frame_gaps == 0
     marked = raw.copy()
     marked[3 * 8032 + 3] |= 0x80                                  # invalid bit of frame 3
-    w1 = marked[5 * 8032 + 4: 5 * 8032 + 8].view("<u4")
-    w1[0] = (w1[0] & 0xFF000000) | 1234                            # frame number jump at frame 5
+    marked = np.concatenate([marked[: 7 * 8032], marked[9 * 8032:]])   # frames 7 and 8 are missing
+    ocfg = pu.oracle_cfg(16.0, 32, 0.012, freq_res=64)
+    ref = o.channelise(marked, ocfg)
+    assert ocfg.result["frame_counters"] == dict(gaps=1, filled=2, invalid=1)
     with ch.Channeliser(cfg, emu_lib) as c:
         got = c.channelise_bytes(marked)
         info = c.get_info()
-    assert got == clean                                            # payload untouched: same output
-    assert info.frames_invalid == 1 and info.frame_gaps == 2       # jump in and out of the odd frame number
+    assert info.frames_invalid == 1 and info.frame_gaps == 1 and info.frames_filled == 2
+    assert len(got) == len(clean)                                  # same number of samples: the gap was filled
+    pu.check_codes(ref, got, ocfg)
+    fg, fc = sigproc.read_fil(got), sigproc.read_fil(clean)
+    assert np.count_nonzero(fg.data != fc.data) > 1000             # ... and the zeroed frames do change the output
+    # the same pushed in ragged pieces (a gap may fall on a push boundary)
+    with ch.Channeliser(cfg, emu_lib) as c:
+        pos, body = 0, bytearray()
+        for n in (5000, 8032 * 7 - 5000 + 11, 9000, marked.size):
+            c.push(marked[pos:pos + n])
+            pos += n
+            body += c.pull()
+        c.flush()
+        body += c.pull()
+        assert c.sigproc_header() + bytes(body) == got
+    # whole-file path: an input with missing frames takes the stream path (gap filling), one with invalid flags only
+    # stays on the overlapped path
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        for name, data in (("gaps.vdif", marked), ("invalid.vdif", np.concatenate([marked[: 7 * 8032], raw[7 * 8032:]]))):
+            path = os.path.join(d, name)
+            data.tofile(path)
+            oc = pu.oracle_cfg(16.0, 32, 0.012, freq_res=64)
+            want = o.channelise(data, oc)
+            with ch.Channeliser(cfg, emu_lib) as c:
+                c.run_file(path, os.path.join(d, name + ".fil"))
+                assert c.get_info().frames_invalid == 1
+            pu.check_codes(want, open(os.path.join(d, name + ".fil"), "rb").read(), oc)
     broken = raw.copy()
     broken[7 * 8032 + 8: 7 * 8032 + 11] = 0                        # frame length field zeroed
     with ch.Channeliser(cfg, emu_lib) as c:

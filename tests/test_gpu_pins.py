@@ -312,3 +312,45 @@ def test_reset_waits_for_the_callers_stream(hip_lib):
     for off, sc, codes in results[1:]:
         assert np.array_equal(off, results[0][0]) and np.array_equal(sc, results[0][1])
         assert np.array_equal(codes, results[0][2])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# invalid frames and missing frames (extract_baseband_chunk.py:56-69 reads the same header fields)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pol,via_file", [(2, False), (4, True), (2, True)])
+def test_dropped_and_invalid_frames(hip_lib, tmp_path, pol, via_file):
+    """config-2 shape, 4 blocks: three frames dropped inside block 1 (the stream path fills them with zero frames so
+    that every later sample keeps its time), one frame flagged invalid inside block 2 (read as zero voltages); blocks
+    0 and 3 are clean and keep the fast kernels, the touched blocks take the generic K1 with the frame mask"""
+    raw = synth.make_vdif(0.27, bw_mhz=32.0, nchan=1024)
+    nfr = raw.size // 8032
+    fr = raw.reshape(nfr, 8032).copy()
+    fr[700, 3] |= 0x80                                             # block 2 (frames 524..786): invalid
+    keep = np.ones(nfr, bool)
+    keep[[300, 301, 302]] = False                                  # block 1 (frames 262..524): three frames missing
+    hurt = fr[keep].reshape(-1)
+    ocfg = pu.oracle_cfg(32.0, 1024, 0.27, pol=pol)
+    ref = o.channelise(hurt, ocfg)
+    assert ocfg.result["frame_counters"] == dict(gaps=1, filled=3, invalid=1)
+    cfg = pu.lib_cfg(hip_lib, 32.0, 1024, 0.27, pol=pol)
+    with ch.Channeliser(cfg, hip_lib) as c:
+        if via_file:
+            vd = str(tmp_path / "hurt.vdif")
+            hurt.tofile(vd)
+            c.run_file(vd, str(tmp_path / "hurt.fil"))
+            got = open(str(tmp_path / "hurt.fil"), "rb").read()
+        else:
+            got = c.channelise_bytes(hurt)
+        info = c.get_info()
+    assert (info.frames_invalid, info.frame_gaps, info.frames_filled) == (1, 1, 3)
+    pu.check_codes(ref, got, ocfg)
+    # only invalid flags (no gap): the overlapped whole-file path keeps running and masks the frame
+    inv = fr.reshape(-1)
+    ocfg2 = pu.oracle_cfg(32.0, 1024, 0.27, pol=pol)
+    ref2 = o.channelise(inv, ocfg2)
+    vd = str(tmp_path / "inv.vdif")
+    inv.tofile(vd)
+    with ch.Channeliser(cfg, hip_lib) as c:
+        c.run_file(vd, str(tmp_path / "inv.fil"))
+        assert c.get_info().frames_invalid == 1 and c.get_info().frames_filled == 0
+    pu.check_codes(ref2, open(str(tmp_path / "inv.fil"), "rb").read(), ocfg2)
