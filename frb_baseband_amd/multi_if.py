@@ -64,37 +64,70 @@ def _header_bytes(h: dict) -> bytes:
     return out + _put_str("HEADER_END")
 
 
-def splice(inputs, out_path: str | None = None) -> bytes:
+def _open_fil(x):
+    """(header dict, header length, total bytes, reader(offset, n) -> bytes) of a path or a bytes object"""
+    if isinstance(x, (bytes, bytearray)):
+        buf = bytes(x)
+        hdr, pos = sigproc.parse_header(buf)
+        return hdr, pos, len(buf), (lambda off, n: buf[off:off + n]), None
+    f = open(x, "rb")
+    head = f.read(4096)
+    hdr, pos = sigproc.parse_header(head)
+    size = os.fstat(f.fileno()).st_size
+
+    def rd(off, n):
+        f.seek(off)
+        return f.read(n)
+    return hdr, pos, size, rd, f
+
+
+def splice(inputs, out_path: str | None = None, block_rows: int = 4096):
     """Frequency-concatenate per-IF filterbanks given in DESCENDING frequency order (the order of
     base2fil.sh's splice_list).  ``inputs``: paths or bytes.  Rows are cut to the shortest input.
-    Output: one SIGPROC file, nchans = sum, fch1 of the first input, [t][product][IF0 chans, IF1 ...]."""
-    fils = [sigproc.read_fil(x) for x in inputs]
-    first = fils[0].header
-    for f in fils[1:]:
-        for key in ("nbits", "nifs", "tsamp"):
-            if f.header[key] != first[key]:
-                raise ValueError(f"cannot splice: {key} differs ({f.header[key]} vs {first[key]})")
-        if abs(f.header["tstart"] - first["tstart"]) > 0.5 * first["tsamp"] / 86400.0:
-            raise ValueError("cannot splice: tstart differs")
-    nt = min(f.data.shape[0] for f in fils)
-    data = np.concatenate([f.data[:nt] for f in fils], axis=2)   # [t][nifs][sum chans]
-    hdr = dict(first)
-    hdr["nchans"] = int(data.shape[2])
-    nbits = first["nbits"]
-    if nbits == 2:
-        flat = data.reshape(-1, 4).astype(np.uint8)
-        body = (flat[:, 0] | (flat[:, 1] << 2) | (flat[:, 2] << 4) | (flat[:, 3] << 6)).astype(np.uint8).tobytes()
-    elif nbits == 8:
-        body = data.astype(np.uint8).tobytes()
-    elif nbits == 16:
-        body = data.astype("<u2").tobytes()
-    else:
-        body = data.astype("<f4").tobytes()
-    blob = _header_bytes(hdr) + body
-    if out_path:
-        with open(out_path, "wb") as f:
-            f.write(blob)
-    return blob
+    Output: one SIGPROC file, nchans = sum, fch1 of the first input, [t][product][IF0 chans, IF1 ...].
+    Streams ``block_rows`` rows at a time (a scan of 16 IFs x minutes never sits in memory); with ``out_path`` the file
+    is written and its path returned, without it the bytes are returned (tests)."""
+    srcs = [_open_fil(x) for x in inputs]
+    try:
+        first = srcs[0][0]
+        for hdr, *_ in srcs[1:]:
+            for key in ("nbits", "nifs", "tsamp"):
+                if hdr[key] != first[key]:
+                    raise ValueError(f"cannot splice: {key} differs ({hdr[key]} vs {first[key]})")
+            if abs(hdr["tstart"] - first["tstart"]) > 0.5 * first["tsamp"] / 86400.0:
+                raise ValueError("cannot splice: tstart differs")
+        nbits, nifs = first["nbits"], first.get("nifs", 1)
+        # bytes of one product line of each input (2-bit: 4 channels per byte)
+        seg = [hdr["nchans"] * nbits // 8 for hdr, *_ in srcs]
+        if nbits == 2 and any(hdr["nchans"] % 4 for hdr, *_ in srcs):
+            raise ValueError("cannot splice 2-bit files whose channel count is not a multiple of 4")
+        nt = min((size - pos) // (s_ * nifs) for (hdr, pos, size, rd, f), s_ in zip(srcs, seg))
+        out_hdr = dict(first)
+        out_hdr["nchans"] = int(sum(hdr["nchans"] for hdr, *_ in srcs))
+        head = _header_bytes(out_hdr)
+        sink = open(out_path, "wb") if out_path else None
+        chunks = [head]
+        if sink:
+            sink.write(head)
+        for r0 in range(0, nt, block_rows):
+            nr = min(block_rows, nt - r0)
+            parts = []
+            for (hdr, pos, size, rd, f), s_ in zip(srcs, seg):
+                raw = rd(pos + r0 * s_ * nifs, nr * s_ * nifs)
+                parts.append(np.frombuffer(raw, dtype=np.uint8).reshape(nr, nifs, s_))
+            block = np.concatenate(parts, axis=2).tobytes()      # byte-wise: whole bytes per (row, product, IF)
+            if sink:
+                sink.write(block)
+            else:
+                chunks.append(block)
+        if sink:
+            sink.close()
+            return out_path
+        return b"".join(chunks)
+    finally:
+        for *_, f in srcs:
+            if f is not None:
+                f.close()
 
 
 def ifall_name(experiment: str, st: str, scanname: str, pol: int) -> str:

@@ -128,3 +128,32 @@ def test_push_driven_scan_with_small_blocks_and_an_early_interval(emu_lib, tmp_p
     assert got.data.shape == want.shape
     assert np.abs(got.data.astype(int) - want.astype(int)).max() <= 1
     assert np.count_nonzero(got.data != want) <= 1e-4 * want.size
+
+
+def test_splice_streams_row_blocks_and_matches_numpy_concat(tmp_path):
+    """host splice (base2fil.sh:422): block-by-block, all bit widths, unequal lengths, bytes and paths"""
+    rng = np.random.default_rng(3)
+    for nbits, dt in ((8, np.uint8), (16, "<u2"), (32, "<f4"), (2, None)):
+        fils, datas = [], []
+        for i, (nch, nt) in enumerate(((16, 37), (8, 41), (16, 40))):
+            if nbits == 2:
+                codes = rng.integers(0, 4, size=(nt, 2, nch), dtype=np.uint8)
+                body = o.pack_codes(codes, 2)
+                data = codes
+            else:
+                data = (rng.integers(0, 200, size=(nt, 2, nch)).astype(dt))
+                body = data.tobytes()
+            head = o.sigproc_header(telescope="effelsberg", source="x", ra="0:0:0", dec="0:0:0", rawdatafile="x", tstart_mjd=59000.0,
+                                    tsamp_s=1e-4, nbits=nbits if nbits != 32 else -32, fch1=1500.0 - 16 * i, foff=-1.0, nchans=nch, nifs=2)
+            fils.append(head + body)
+            datas.append(data)
+        want = np.concatenate([d[:37] for d in datas], axis=2)
+        got = sigproc.read_fil(multi_if.splice(fils, block_rows=5))
+        assert got.header["nchans"] == 40 and got.header["fch1"] == 1500.0 and got.data.shape == want.shape
+        assert np.array_equal(got.data, want)
+        paths = []
+        for i, blob in enumerate(fils):
+            paths.append(str(tmp_path / f"{nbits}_{i}.fil"))
+            open(paths[-1], "wb").write(blob)
+        out = multi_if.splice(paths, str(tmp_path / f"{nbits}_all.fil"), block_rows=7)
+        assert open(out, "rb").read() == multi_if.splice(fils)
