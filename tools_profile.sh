@@ -1,18 +1,22 @@
 #!/bin/bash
-# Round artifacts (run on the GPU box): bench line, rocprofv3 kernel stats of the same command, HBM traffic PMC passes.
-tag=${1:-r01_final}
+# Round artifacts (run on the GPU box): bench line (with its own live PMC traffic passes and the host-inclusive leg), rocprofv3
+# kernel stats of the same workload, per-kernel HBM traffic from separate PMC passes.
+tag=${1:-r02_final}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/$tag
 mkdir -p $out
-timeout -k 10 400 python3 bench.py > $out/bench.json 2> $out/bench.err
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --no-cpu > $out/trace_bench.json 2> $out/trace.err
-timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py --no-cpu --steps 1 --warmup 1 > $out/fetch.log 2>&1
-timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py --no-cpu --steps 1 --warmup 1 > $out/write.log 2>&1
+timeout -k 10 500 python3 bench.py > $out/bench.json 2> $out/bench.err
+echo "bench done rc=$?"
+plain="--no-cpu --no-host --no-traffic"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py $plain > $out/trace_bench.json 2> $out/trace.err
+echo "trace done rc=$?"
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py $plain --steps 1 --warmup 1 > $out/fetch.log 2>&1
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py $plain --steps 1 --warmup 1 > $out/write.log 2>&1
 python3 - <<PY
 import csv, glob, collections, json
 res = {}
 for name, cnt in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    for p in glob.glob("$out/%s/*/*counter_collection.csv" % name):
+    for p in glob.glob("$out/%s/**/*counter_collection.csv" % name, recursive=True):
         acc = collections.defaultdict(float); n = collections.Counter()
         for row in csv.DictReader(open(p)):
             if row["Counter_Name"] != cnt: continue
@@ -22,6 +26,10 @@ for name, cnt in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
             if "frbch" in k:
                 res.setdefault(k, {})[cnt + "_KB_total"] = acc[k]; res[k]["dispatches"] = n[k]
 json.dump(res, open("$out/pmc_traffic.json", "w"), indent=1)
-print(json.dumps(res, indent=1)[:3000])
+stats = glob.glob("$out/trace/**/*kernel_stats.csv", recursive=True)
+if stats:
+    import shutil
+    shutil.copy(stats[0], "$out/kernel_stats.csv")
+    print(open(stats[0]).read()[:2500])
 PY
-cat $out/bench.json | cut -c1-1800
+cut -c1-2500 $out/bench.json

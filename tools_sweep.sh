@@ -5,7 +5,7 @@ out=gpurun_out/sweep_$tag; mkdir -p $out
 for spec in "$@"; do
   label=${spec%%|*}; args=${spec#*|}; envs=""
   if [[ "$args" == *";"* ]]; then envs=${args%%;*}; args=${args#*;}; fi
-  env $envs timeout -k 10 240 python3 bench.py --no-cpu --steps 5 --warmup 3 $args > $out/$label.json 2> $out/$label.err || { echo "$label FAILED"; tail -3 $out/$label.err; exit 1; }
+  env $envs timeout -k 10 240 python3 bench.py --no-cpu --no-host --no-traffic --steps 5 --warmup 3 $args > $out/$label.json 2> $out/$label.err || { echo "$label FAILED"; tail -3 $out/$label.err; exit 1; }
   python3 - "$label" "$out/$label.json" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1]); r = d["roofline"]; k = r["kernels_ms_per_step"]
