@@ -105,6 +105,12 @@ SYMBOLS = {
                                   C.c_uint32, C.c_uint32, C.c_double, C.c_int, _P, _P, C.c_uint32, C.c_char_p, C.c_size_t]),
     "frbch_fold_device": (C.c_int, [C.POINTER(FrbchFilDesc), _P, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double,
                                     C.c_uint32, C.c_uint32, C.c_double, C.c_int, _P, _P, C.c_uint32, C.c_char_p, C.c_size_t]),
+    "frbch_cornerturn_info": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                        C.POINTER(C.c_uint32), C.c_char_p, C.c_size_t]),
+    "frbch_cornerturn_host": (C.c_int, [C.c_char_p, _P, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(_P), C.c_uint32,
+                                        C.c_size_t, C.c_int, C.c_char_p, C.c_size_t]),
+    "frbch_cornerturn_device": (C.c_int, [C.c_char_p, _P, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(_P), C.c_uint32,
+                                          C.c_size_t, C.c_int, C.c_char_p, C.c_size_t]),
     "frbch_set_profiling": (C.c_int, [_P, C.c_int]),
     "frbch_timing_reset": (C.c_int, [_P]),
     "frbch_get_timing": (C.c_int, [_P, C.POINTER(FrbchTiming)]),

@@ -18,6 +18,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <sstream>
 #include <string>
 #include <condition_variable>
 #include <mutex>

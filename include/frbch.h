@@ -254,6 +254,23 @@ int frbch_fold_device(const frbch_fil_desc* fil, const void* d_rows, uint64_t nr
                       double pepoch_mjd, double dm, uint32_t apply_delays, uint32_t nbin, double subint_s, int device,
                       double* d_profile, uint32_t* d_hits, uint32_t nsub, char* err, size_t err_cap);
 
+/* ---- in front of the filterbank: the corner turn -------------------------------
+ * jive5ab's spif2file splits the recorder's stream -- every W-bit word holds one time sample of ALL channels -- into one
+ * 2-channel stream per IF, driven by the recipe strings of spif2file.sh:31-113, e.g. the 16-channel 2-bit mode
+ * `32>[24,25,16,17][8,9,0,1]...[14,15,6,7]:0-7`: output stream ("tag") g takes the listed bits of every word, in that
+ * order, LSB first; `swap_sign_mag+` (Mark5B modes, :79-94) first exchanges the two bits of every 2-bit sample.  Doing
+ * it on the GPU lets frbch_process_device read the result straight from HBM (header_bytes = 0) without per-IF files.
+ * jive5ab is not in the reference tree: the bit order is this library's restatement (oracle/post_oracle.py). */
+int frbch_cornerturn_info(const char* recipe, uint32_t* word_bits, uint32_t* ntags, uint32_t* bits_per_word,
+                          uint32_t* first_tag, char* err, size_t err_cap);
+/* frames: nframes recorder frames; out[g]: payload bytes of tag first_tag + g, out_bytes_each = words * bits_per_word / 8 */
+int frbch_cornerturn_host(const char* recipe, const void* frames, size_t nframes, uint32_t frame_bytes,
+                          uint32_t header_bytes, void* const* out, uint32_t ntags, size_t out_bytes_each, int device,
+                          char* err, size_t err_cap);
+int frbch_cornerturn_device(const char* recipe, const void* d_frames, size_t nframes, uint32_t frame_bytes,
+                            uint32_t header_bytes, void* const* d_out, uint32_t ntags, size_t out_bytes_each, int device,
+                            char* err, size_t err_cap);
+
 /* ---- measurement -------------------------------------------------------------------------- */
 int frbch_set_profiling(frbch_handle* h, int enable);
 int frbch_timing_reset(frbch_handle* h);

@@ -111,3 +111,40 @@ def fold(x, *, fch1, foff, tsamp, tstart_mjd, f0, f1, pepoch_mjd, dm, nbin, subi
         prof[:, c, :] = np.bincount(flat, weights=x[:, c], minlength=nsub * nbin).reshape(nsub, nbin)
         hits[:, c, :] = np.bincount(flat, minlength=nsub * nbin).reshape(nsub, nbin)
     return prof, hits
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# corner turn (spif2file.sh:31-113): jive5ab is absent; the bit order restated here is the contract of frbch_cornerturn_*
+# --------------------------------------------------------------------------------------------------------------------
+def parse_recipe(recipe: str):
+    swap = recipe.startswith("swap_sign_mag+")
+    if swap:
+        recipe = recipe[len("swap_sign_mag+"):]
+    w, rest = recipe.split(">", 1)
+    body, _, tags = rest.partition(":")
+    groups = [[int(b) for b in g.split(",")] for g in body.strip("[]").split("][")]
+    return int(w), groups, swap
+
+
+def cornerturn(payload: np.ndarray, recipe: str):
+    """payload bytes of the recorder stream -> list of per-tag payload byte arrays (output bit k of group g of word i =
+    input bit groups[g][k] of word i; everything LSB first)"""
+    w, groups, swap = parse_recipe(recipe)
+    bits = np.unpackbits(payload, bitorder="little")
+    words = bits.reshape(-1, w)
+    if swap:
+        words = words.reshape(-1, w // 2, 2)[:, :, ::-1].reshape(-1, w)
+    return [np.packbits(words[:, g].reshape(-1), bitorder="little") for g in groups]
+
+
+def interleave(streams, recipe: str):
+    """inverse of cornerturn: per-tag payloads -> recorder payload (unlisted bits zero)"""
+    w, groups, swap = parse_recipe(recipe)
+    glen = len(groups[0])
+    nwords = streams[0].size * 8 // glen
+    words = np.zeros((nwords, w), np.uint8)
+    for g, s in zip(groups, streams):
+        words[:, g] = np.unpackbits(s, bitorder="little").reshape(nwords, glen)
+    if swap:
+        words = words.reshape(-1, w // 2, 2)[:, :, ::-1].reshape(-1, w)
+    return np.packbits(words.reshape(-1), bitorder="little")
