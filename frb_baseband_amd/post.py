@@ -286,3 +286,38 @@ def fold_fil(filterbankfile: str, parfile: str, nbin: int = 0, subint_s: float =
     wf = (wf - wf.min()) / max(1e-30, wf.max() - wf.min())
     write_png(base + ".png", np.concatenate([strip, wf], axis=0))
     return base + ".ar", profile
+
+
+def main(argv=None):
+    """``python -m frb_baseband_amd.post fold <fil> <par> [...]`` / ``... prepdata <fil> --dm <dm> [...]``: the two stages
+    as commands, for the places where base2fil.sh / process_vdif.py launch dspsr and prepdata"""
+    import argparse
+    ap = argparse.ArgumentParser(prog="frb_baseband_amd.post")
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    f = sub.add_parser("fold", help="fold a filterbank with a .par file (base2fil.sh:465-493)")
+    f.add_argument("fil")
+    f.add_argument("par")
+    f.add_argument("--nbin", type=int, default=0, help="phase bins (0: largest power of two <= period / tsamp, at most 1024)")
+    f.add_argument("-L", "--subint", type=float, default=10.0, help="sub-integration length, s (dspsr -L 10)")
+    f.add_argument("--fscrunch", type=int, default=128, help='channels of the plot (psrplot -j "fscrunch 128")')
+    f.add_argument("--device", type=int, default=int(os.environ.get("FRBCH_DEVICE", "0")))
+    d = sub.add_parser("prepdata", help="incoherent dedispersion (process_vdif.py:202-229)")
+    d.add_argument("fil")
+    d.add_argument("--dm", type=float, required=True)
+    d.add_argument("--dm2", type=float, default=0.0)
+    d.add_argument("--dmstep", type=float, default=1.0)
+    d.add_argument("--nozerodm", action="store_false", help="do not subtract the zero-DM series")
+    d.add_argument("--clip", type=float, default=5.0)
+    d.add_argument("--device", type=int, default=int(os.environ.get("FRBCH_DEVICE", "0")))
+    a = ap.parse_args(argv)
+    if a.cmd == "fold":
+        ar, profile = fold_fil(a.fil, a.par, nbin=a.nbin, subint_s=a.subint, fscrunch_to=a.fscrunch, device=a.device)
+        print("wrote {0}, {1}.profile.txt, {1}.png; peak bin {2} of {3}".format(ar, a.fil, int(np.argmax(profile)), profile.size))
+    else:
+        for path in prepdata_gpu(a.fil, a.dm, zerodm=a.nozerodm, clip=a.clip, dm2=a.dm2, dmstep=a.dmstep, device=a.device):
+            print("wrote", path)
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

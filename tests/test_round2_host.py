@@ -1,6 +1,7 @@
 """Round-2 host-side checks that need no GPU: ABI v2 fields, flag hygiene, error classes, the IQUV and level-table
 extensions and the unpack tap through the TEST-ONLY emulator build, scan buffer sizing of the push-driven fallback."""
 import ctypes as C
+import json
 import os
 
 import numpy as np
@@ -157,3 +158,36 @@ def test_splice_streams_row_blocks_and_matches_numpy_concat(tmp_path):
             open(paths[-1], "wb").write(blob)
         out = multi_if.splice(paths, str(tmp_path / f"{nbits}_all.fil"), block_rows=7)
         assert open(out, "rb").read() == multi_if.splice(fils)
+
+
+def test_bench_launcher_starts_ranks_without_touching_the_gpu():
+    """`bench.py --gpus 2` with no WORLD_SIZE: the parent only launches two fresh rank processes (here, without a GPU, every
+    rank exits 2 with the loud no-fallback message) and fails the run; it never imports torch or initialises HIP itself"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "1", "--warmup", "0",
+                        "--no-cpu", "--no-host", "--seconds", "0.2"], env=env, capture_output=True, text=True, timeout=600)
+    import torch
+    if torch.cuda.is_available():
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert r.returncode == 0 and line["n_gpus"] == 2 and len(line["config"]["per_rank_seconds"]) == 2
+    else:
+        assert r.returncode != 0 and "rank exit codes [2, 2]" in r.stderr
+
+
+def test_post_command_line(emu_lib, tmp_path, monkeypatch):
+    from frb_baseband_amd import post
+    from tests.test_post import HDR, P0, DM0, pulse_train_rows
+    monkeypatch.setattr(post._lib, "load", lambda path=None: emu_lib)
+    x = pulse_train_rows(6000, HDR)
+    fil = str(tmp_path / "a.fil")
+    head = o.sigproc_header(telescope="effelsberg", source="J0000+00", ra="0:0:0", dec="0:0:0", rawdatafile="x", tstart_mjd=HDR["tstart"],
+                            tsamp_s=HDR["tsamp"], nbits=8, fch1=HDR["fch1"], foff=HDR["foff"], nchans=64, nifs=1)
+    open(fil, "wb").write(head + x.tobytes())
+    par = tmp_path / "a.par"
+    par.write_text("PSRJ J0000+00\nP0 %.6f\nDM %.1f\n" % (P0, DM0))
+    assert post.main(["fold", fil, str(par), "--nbin", "64", "-L", "0.2"]) == 0 and os.path.exists(fil + ".ar")
+    assert post.main(["prepdata", fil, "--dm", "10", "--dm2", "11", "--clip", "0"]) == 0
+    assert os.path.exists(str(tmp_path / "a_DM10.00.dat")) and os.path.exists(str(tmp_path / "a_DM11.00.inf"))
