@@ -33,6 +33,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
+# fp32 vector peak in lane operations: 157.3 TFLOP/s (spec, FMA = 2) / 2 = 78.6 T lane-ops/s; tools_micro/valu_peak measures
+# 71 - 75 T/s for v_add / v_sub streams at 16 waves per CU, 63 at 8 (a packed v_pk_* counts 2 and issues at half the rate)
+VALU_PEAK_TLOPS = 78.65
+# static VALU instruction count per wave and filterbank block of the dominant kernels (llvm-objdump of the loop body;
+# SQ_INSTS_VALU of tools_pmc.sh agrees): waves per workgroup x workgroups per block follow from the geometry
+VALU_PER_WAVE_BLOCK = {"frbch_k1_wave<3,8,1>": (2424, 8)}
 
 
 def synth_frames_device(torch, dev, seconds: float, bw_mhz: float, nchan: int, if_index: int, payload: int = 8000):
@@ -396,12 +402,20 @@ def main():
         traffic = None
         if live_traffic and name in live_traffic:
             traffic = live_traffic[name]
+        valu = None
+        if name in VALU_PER_WAVE_BLOCK and rec["total_ms"] > 0:     # the other roof of this kernel: fp32 VALU lane operations
+            per_wave, waves = VALU_PER_WAVE_BLOCK[name]
+            lane_ops = per_wave * waves * 64.0 * (2 * args.nchan // 8) * nblocks * rec["launches"]
+            tl = lane_ops / (rec["total_ms"] * 1e-3) / 1e12
+            valu = {"bound": "valu", "achieved": round(tl, 2), "peak": VALU_PEAK_TLOPS, "unit": "T lane-ops/s (fp32, unpacked)",
+                    "frac": round(tl / VALU_PEAK_TLOPS, 4), "instructions_per_wave_and_block": per_wave}
         roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "traffic_source": (live_traffic or {}).get("_source"),
                 "avg_launch_ms": round(rec["total_ms"] / max(1, rec["launches"]), 5),
                 "algorithmic_bytes_per_launch": rec["algorithmic_bytes"] / max(1, rec["launches"]),
                 "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in timing.items()},
+                "valu": valu,
                 "whole_path": {"algorithmic_bytes_per_sample": 17.0 if args.pol < 4 else 18.5,
                                "achieved": round(value / world * 1e6 * (17.0 if args.pol < 4 else 18.5) / 1e9, 1),
                                "frac": round(value / world * 1e6 * (17.0 if args.pol < 4 else 18.5) / 1e9 / HBM_PEAK_GBS, 4)}}
