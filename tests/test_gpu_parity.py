@@ -76,18 +76,18 @@ CASES = [
     (32.0, 2048, 0.6, dict(dm=56.7, coherent=1, freq=1400.0, start=2 / 64e6)),  # -S off the K1 piece boundary: falls back to the generic K1 / K3, kernel table rebuilt
     (16.0, 256, 0.2, dict(dm=20.0, coherent=1, freq=600.0, pol=0, nbit=16)),     # M = 2 / 2
     (64.0, 4096, 1.1, dict(tscr=8)),                         # BASELINE config 4 shape (-t 8 -F4096:8192), 2 blocks: M = 32 barrier kernels, K2 walks 4 sub-tiles
-    (64.0, 4096, 1.1, dict(tscr=8, flags=3)),                # the same through the generic kernels
-    (-64.0, 4096, 1.1, {}),                                  # M = 32, -t 1, LSB
-    (64.0, 4096, 1.1, dict(flags=1 << 21, tscr=2)),          # M = 32 with the slab layout of the spill instead of chunks of eight time samples
-    (64.0, 4096, 1.1, dict(pol=4, tscr=2, nbit=16)),         # M = 32, coherency products
-    (64.0, 4096, 1.1, dict(pol=4, tscr=4)),                  # four products and tscrunch > 2: generic K2 behind the M = 32 K1
+    (64.0, 4096, 0.55, dict(tscr=8, flags=3)),                # the same through the generic kernels
+    (-64.0, 4096, 0.55, {}),                                  # M = 32, -t 1, LSB
+    (64.0, 4096, 0.55, dict(flags=1 << 21, tscr=2)),          # M = 32 with the slab layout of the spill instead of chunks of eight time samples
+    (64.0, 4096, 0.55, dict(pol=4, tscr=2, nbit=16)),         # M = 32, coherency products
+    (64.0, 4096, 0.55, dict(pol=4, tscr=4)),                  # four products and tscrunch > 2: generic K2 behind the M = 32 K1
     # Stokes I,Q,U,V (pol_mode 5, the `-d4 -iquv` extension; north_star "IQUV formation") through every K2 family
     (32.0, 1024, 0.14, dict(pol=5)),                         # wave K2, MSTAT instantiation while the interval is measured
     (-32.0, 1024, 0.14, dict(pol=5, tscr=2, nbit=16)),
     (32.0, 1024, 0.14, dict(pol=5, flags=8, tscr=4)),        # barrier K2
     (32.0, 1024, 0.14, dict(pol=5, flags=2)),                # generic K2
     (16.0, 128, 0.05, dict(pol=5, tscr=8, nbit=-32)),        # 2C = 256 wave K2
-    (64.0, 4096, 1.1, dict(pol=5, tscr=2)),                  # M = 32
+    (64.0, 4096, 0.55, dict(pol=5, tscr=2)),                  # M = 32
     (-32.0, 512, 0.15, dict(dm=26.7, coherent=1, freq=350.0, pol=5, tscr=2)),   # K3 (register passes)
 ]
 
