@@ -18,6 +18,8 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <sstream>
 #include <string>
 #include <condition_variable>
@@ -1779,7 +1781,37 @@ int run_pipelined(frbch_handle* const* hs, uint32_t nif, const int* in_fds, int 
     for (const Batch& b : batches[i]) in_total += b.nfr * hs[i]->v0.frame_bytes;
   const int NR = (int)std::min<uint64_t>(kMaxSlots, std::max<uint64_t>(2, (in_total + in_cap - 1) / in_cap));
   const int NSO = NR;                                   // output slots
-  const int NWR = 1;                                    // writer threads
+  // A regular output file of known size is preallocated (posix_fallocate, in a thread of its own while the input is
+  // being read) and then written through a shared mapping by one writer per slot: the pages exist, the writers' copies
+  // only map them (minor faults run in parallel; measured on tmpfs: fallocate 29 ms + 8 copying threads 27 ms for 319 MB,
+  // against 75 ms for write() calls and 110+ ms for copies that have to allocate the pages in their faults).  Anything
+  // else -- FIFOs (base2fil.sh:348-349), character devices -- keeps ONE writer and strictly sequential write() calls.
+  struct stat ost;
+  const bool out_regular = fstat(out_fd, &ost) == 0 && S_ISREG(ost.st_mode);
+  uint64_t out_expect = 0;
+  if (out_regular) {
+    uint64_t rows_min = UINT64_MAX;
+    for (uint32_t i = 0; i < nif; ++i) {
+      uint64_t nb = 0;
+      for (const Batch& b : batches[i]) nb += b.nb;
+      rows_min = std::min<uint64_t>(rows_min, nb * hs[i]->pl.rows_per_block);
+    }
+    const size_t hdr_bytes = sigproc_header(h0->cfg, h0->pl, 0.0, scan ? (int)(h0->pl.c * nif) : 0).size();
+    out_expect = hdr_bytes + rows_min * (scan ? (uint64_t)row_pitch : h0->pl.row_bytes);
+    if (out_expect < (8u << 20)) out_expect = 0;        // small outputs: not worth a mapping
+  }
+  uint8_t* omap = nullptr;                              // set by the preallocation thread
+  std::atomic<int> pre_done{out_expect ? 0 : 1};
+  std::thread prealloc;
+  if (out_expect)
+    prealloc = std::thread([&]() {
+      if (posix_fallocate(out_fd, 0, (off_t)out_expect) == 0) {
+        void* m = mmap(nullptr, (size_t)out_expect, PROT_READ | PROT_WRITE, MAP_SHARED, out_fd, 0);
+        if (m != MAP_FAILED) omap = (uint8_t*)m;
+      }
+      pre_done.store(1, std::memory_order_release);    // (without a mapping the writers fall back to positional writes)
+    });
+  const int NWR = out_expect ? NSO : 1;                 // writer threads (each owns one slot when the output is mapped)
   if (h0->pin_in_cap < in_cap || h0->pin_out_cap < out_cap) {
     for (int i = 0; i < kMaxSlots; ++i) {
       dev_host_free(h0->pin_in[i]); h0->pin_in[i] = nullptr;
@@ -1842,7 +1874,7 @@ int run_pipelined(frbch_handle* const* hs, uint32_t nif, const int* in_fds, int 
       }
     });
   for (int w = 0; w < NWR; ++w)
-    writers.emplace_back([&, w]() {                // one writer, slots in order
+    writers.emplace_back([&, w]() {                // mapped output: writer w owns slot w; else one writer, slots in order
       for (size_t i = (size_t)w;; i += (size_t)NWR) {
         const int slot = (int)(i % (size_t)NSO);
         size_t n;
@@ -1854,8 +1886,14 @@ int run_pipelined(frbch_handle* const* hs, uint32_t nif, const int* in_fds, int 
           n = qout.nbytes[slot];
           off = qout.offs[slot];
         }
-        (void)off;
-        const bool ok = write_all(out_fd, outbuf[slot], n);
+        bool ok = true;
+        if (NWR > 1) {
+          while (!pre_done.load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+          if (omap && off + n <= out_expect) memcpy(omap + off, outbuf[slot], n);
+          else ok = pwrite_all(out_fd, outbuf[slot], n, off);
+        } else {
+          ok = write_all(out_fd, outbuf[slot], n);
+        }
         const int err = ok ? 0 : (errno ? errno : EIO);
         std::lock_guard<std::mutex> lk(qout.m);
         if (!ok) qout.error = err;
@@ -2023,6 +2061,10 @@ int run_pipelined(frbch_handle* const* hs, uint32_t nif, const int* in_fds, int 
     for (auto& t : writers) t.join();
     if (!rc && qout.error) rc = fail(h0, FRBCH_E_IO, std::string("write: ") + strerror(qout.error));
   }
+  if (prealloc.joinable()) prealloc.join();
+  if (omap) munmap(omap, (size_t)out_expect);
+  if (out_expect && out_off != out_expect && ftruncate(out_fd, (off_t)out_off) != 0 && !rc)
+    rc = fail(h0, FRBCH_E_IO, std::string("ftruncate: ") + strerror(errno));
   PHASE_MARK(pc, "writers drained");
   release();
   return rc;

@@ -191,3 +191,22 @@ def test_post_command_line(emu_lib, tmp_path, monkeypatch):
     assert post.main(["fold", fil, str(par), "--nbin", "64", "-L", "0.2"]) == 0 and os.path.exists(fil + ".ar")
     assert post.main(["prepdata", fil, "--dm", "10", "--dm2", "11", "--clip", "0"]) == 0
     assert os.path.exists(str(tmp_path / "a_DM10.00.dat")) and os.path.exists(str(tmp_path / "a_DM11.00.inf"))
+
+
+def test_whole_file_path_with_a_mapped_output_equals_the_stream_path(emu_lib, tmp_path):
+    """outputs of 8 MB and more are preallocated and written through a shared mapping by one writer per slot: same
+    bytes as push / pull, file length exact, also when rows are emitted interval by interval"""
+    raw = synth.make_vdif(0.56, bw_mhz=16.0, nchan=32)
+    vd = str(tmp_path / "big.vdif")
+    raw.tofile(vd)
+    for const, interval in ((1, 10.0), (0, 0.05)):
+        cfg = pu.lib_cfg(emu_lib, 16.0, 32, 0.56, freq_res=64, const=const, interval=interval)
+        with ch.Channeliser(cfg, emu_lib) as c:
+            want = c.channelise_bytes(raw)
+        assert len(want) > (8 << 20)
+        out = str(tmp_path / f"big_{const}.fil")
+        with ch.Channeliser(cfg, emu_lib) as c:
+            c.run_file(vd, out)
+            c.reset()
+            c.run_file(vd, out)                   # again into the existing file (O_TRUNC, then preallocated anew)
+        assert open(out, "rb").read() == want
