@@ -178,8 +178,16 @@ def launch_ranks(args, argv):
         print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
         sys.stdout.write(out0 or "")
         return 1
-    sys.stdout.write(out0)
-    sys.stdout.flush()
+    # ONE JSON line: whatever else a rank printed on stdout (gloo's connection banner in the one-GPU rehearsal) goes to stderr
+    lines = (out0 or "").splitlines()
+    keep = [ln for ln in lines if ln.startswith('{"metric"')]
+    for ln in lines:
+        if not ln.startswith('{"metric"'):
+            print(ln, file=sys.stderr)
+    if not keep:
+        print("bench.py: rank 0 printed no result line", file=sys.stderr)
+        return 1
+    print(keep[-1], flush=True)
     return 0
 
 
