@@ -215,7 +215,7 @@ def collect_traffic(argv):
             cmd = ["rocprofv3", "--pmc", cnt, "--output-format", "csv", "-d", d, "--", sys.executable,
                    os.path.abspath(__file__)] + child + ["--pmc-child"]
             env = dict(os.environ, TMPDIR="/tmp")
-            pr = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+            pr = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150)
             if pr.returncode != 0:
                 return None
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
