@@ -128,3 +128,29 @@ def test_known_pulsar_flow_end_to_end(hip_lib, tmp_path):
     hi = np.nonzero(y > np.median(y) + 0.5 * (y.max() - np.median(y)))[0]
     starts = hi[np.insert(np.diff(hi) > 100, 0, True)]
     assert len(starts) >= 25 and np.all(np.abs(np.diff(starts) * tsamp - P0) < 3 * tsamp)
+
+
+def test_config5_as_stated(hip_lib, tmp_path):
+    """BASELINE.json configs[4] at its own shape: 32 MHz at 1.4 GHz, `-F2048:4096 -D 56.7 -F2048:D` (the golden command
+    line of the harness), 2 coherent blocks with overlap-save, then the fold of the .fil with a .par file."""
+    bw, freq, nchan = 32.0, 1400.0, 2048
+    raw = _dispersed_pulsar_vdif(0.7, bw, freq, DM0, P0, seed=21)
+    vd = str(tmp_path / "pr001a_ef_no0001_IF1.vdif")
+    raw.tofile(vd)
+    hdr = pv.make_hdr("J0000+00", freq, vd, pol=2, usb=True, ra="00:00:00", dec="00:00:00", bw=bw, telescope="effelsberg")
+    log = io.StringIO()
+    with contextlib.redirect_stdout(log):
+        fil = pv.run_digifil(hdr, str(tmp_path), 0, 0.7, nchan, overwrite=True, pol=2, nbit=8, dm=DM0, coherent=True)
+    assert "-d1 -F2048:4096 -D 56.7 -F2048:D" in log.getvalue()
+    f = sigproc.read_fil(fil)
+    assert f.header["nchans"] == 2048 and f.header["refdm"] == DM0 and f.data.shape[0] >= 2 * 4000
+    par = tmp_path / "J0000+00.psrcat.par"
+    par.write_text("PSRJ J0000+00\nP0 %.6f\nDM %.1f\n" % (P0, DM0))
+    ar, profile = post.fold_fil(fil, str(par), nbin=128, subint_s=10.0, lib=hip_lib)
+    peak = int(np.argmax(profile))
+    off = np.delete(profile, [(peak - 1) % 128, peak, (peak + 1) % 128])
+    snr = (profile[peak] - off.mean()) / off.std()
+    print("config 5 as stated: peak bin", peak, "S/N", round(float(snr), 1))
+    assert snr > 20
+    assert profile[(peak + 2) % 128] - off.mean() < 0.15 * (profile[peak] - off.mean())
+    assert profile[(peak - 2) % 128] - off.mean() < 0.15 * (profile[peak] - off.mean())
