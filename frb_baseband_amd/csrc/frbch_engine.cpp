@@ -332,6 +332,7 @@ void launch_k1_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
 constexpr uint32_t kFusedStatWgs = 2048;   // persistent K2 workgroups (= rows of partial sums per thread row) while statistics are fused
 // threads per workgroup of the wave-private K2 variant launch_k2_wave_t selects
 int k2_wave_nt(const Plan& pl, uint32_t h_flags) {
+  if (pl.fast_k2_log2m == 5) return 512;
   if (pl.fast_k2_log2m == 4) return pl.fast_k2_nw == 2 ? 256 : 512;
   if (pl.fast_k2_nw == 8) return 512;
   if (pl.fast_k2_log2m == 3 && !(h_flags & 32u)) return pl.fast_k2_nw == 2 ? 256 : 512;
@@ -343,7 +344,9 @@ int fused_stat_chunks(const Plan& pl, uint32_t h_flags, int pol_mode) {
   if (!(pl.fast_k2_log2m || pl.fast_k2_m1) || !pl.fast_k2_wave || pl.coherent || (h_flags & (1u << 20))) return 0;
   const int nt = k2_wave_nt(pl, h_flags), cg = (int)(pl.ncol / 4);
   if (cg > nt)   // a thread owns cg/nt column groups, one row of sums per workgroup (the MSTAT instantiations: 2C = 2048, two waves per sequence)
-    return (cg % nt == 0 && cg / nt <= 4 && pl.fast_k2_log2m == 3 && !(h_flags & 32u) && pl.fast_k2_nw != 8) ? (int)kFusedStatWgs : 0;
+    return (cg % nt == 0 && cg / nt <= 4)
+               ? (pl.fast_k2_log2m == 5 ? 256 : ((pl.fast_k2_log2m == 3 && !(h_flags & 32u) && pl.fast_k2_nw != 8) ? (int)kFusedStatWgs : 0))   // 2C = 8192: resident workgroups only
+               : 0;
   if (nt % cg != 0) return 0;
   return (int)kFusedStatWgs * (nt / cg);
 }
@@ -364,6 +367,14 @@ void launch_k2_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s, u
   const dim3 grid2 = pers(pl.r / (2 * spw)), grid4 = pers(pl.r / (4 * spw)), grid8 = pers(pl.r / (8 * spw));
   const int pm = p.pol_mode == 2 ? 2 : (p.pol_mode >= 4 ? 4 : 0);
 #define FRBCH_K2W(NWV, PMV, GRID) hipLaunchKernelGGL((fast::frbch_k2_wave<LOG2M, NWV, PMV>), GRID, dim3(64 * NWV), pl.k2_fast_lds, s, p)
+  if constexpr (LOG2M == 5) {   // 2C = 8192: two time samples per workgroup (32-byte pieces of the spill lines), four waves and two virtual threads per lane each; one workgroup per CU
+    const dim3 grid1 = dim3(std::min<uint64_t>((uint64_t)(pl.r / 2) * nb, p.stat_partial ? 256u : 1024u));   // (multiples of 8: XCD-aware tile order)
+    // (the instantiation that keeps the rescale sums only while an interval is being measured)
+    if (pm == 2 && p.stat_partial) hipLaunchKernelGGL((fast::frbch_k2_wave<5, 8, 2, 4, true>), grid1, dim3(512), pl.k2_fast_lds, s, p);
+    else if (pm == 2) hipLaunchKernelGGL((fast::frbch_k2_wave<5, 8, 2, 4>), grid1, dim3(512), pl.k2_fast_lds, s, p);
+    else if (p.stat_partial) hipLaunchKernelGGL((fast::frbch_k2_wave<5, 8, 0, 4, true>), grid1, dim3(512), pl.k2_fast_lds, s, p);
+    else hipLaunchKernelGGL((fast::frbch_k2_wave<5, 8, 0, 4>), grid1, dim3(512), pl.k2_fast_lds, s, p);
+  } else
   if constexpr (LOG2M == 4) {   // 2C = 4096: two waves per sequence; 2 or 4 sequences per workgroup
     if (pl.fast_k2_nw == 2) {
       if (pm == 2) hipLaunchKernelGGL((fast::frbch_k2_wave<4, 4, 2, 2>), grid2, dim3(256), pl.k2_fast_lds, s, p);
@@ -544,6 +555,7 @@ bool launch_k2_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
       case 2: launch_k2_wave_t<2>(pl, p, nb, s, h->cfg.flags); break;
       case 3: launch_k2_wave_t<3>(pl, p, nb, s, h->cfg.flags); break;
       case 4: launch_k2_wave_t<4>(pl, p, nb, s, h->cfg.flags); break;
+      case 5: launch_k2_wave_t<5>(pl, p, nb, s, h->cfg.flags); break;
       default: return false;
     }
     return true;
@@ -726,6 +738,12 @@ int setup_fast(frbch_handle* h) {
 #define FRBCH_ALLOW_SEL(a, b, c, d, NAME, ...) NAME
 #define FRBCH_ALLOW3(L, NWV, PMV) FRBCH_ALLOW_(L, NWV, PMV, 1)
 #define FRBCH_ALLOW_L(L) FRBCH_ALLOW(L, 2, 0); FRBCH_ALLOW(L, 2, 2); FRBCH_ALLOW(L, 2, 4); FRBCH_ALLOW(L, 4, 0); FRBCH_ALLOW(L, 4, 2); FRBCH_ALLOW(L, 4, 4); FRBCH_ALLOW(L, 8, 0); FRBCH_ALLOW(L, 8, 2); FRBCH_ALLOW(L, 8, 4)
+      if (pl.fast_k2_log2m == 5) {
+        if (!rc) rc = allow_lds(h, fast::frbch_k2_wave<5, 8, 2, 4, true>, pl.k2_fast_lds);
+        if (!rc) rc = allow_lds(h, fast::frbch_k2_wave<5, 8, 0, 4, true>, pl.k2_fast_lds);
+        if (!rc) rc = allow_lds(h, fast::frbch_k2_wave<5, 8, 2, 4>, pl.k2_fast_lds);
+        if (!rc) rc = allow_lds(h, fast::frbch_k2_wave<5, 8, 0, 4>, pl.k2_fast_lds);
+      } else
       if (pl.fast_k2_log2m == 4) {
         FRBCH_ALLOW(4, 4, 0, 2); FRBCH_ALLOW(4, 4, 2, 2); FRBCH_ALLOW(4, 4, 4, 2);
         FRBCH_ALLOW(4, 8, 0, 2); FRBCH_ALLOW(4, 8, 2, 2); FRBCH_ALLOW(4, 8, 4, 2);
@@ -1144,7 +1162,8 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
         const bool two = (pl.fast_k2_log2m == 4) || (pl.fast_k2_log2m == 3 && !(h->cfg.flags & 32u) && pl.fast_k2_nw != 8);
         const int nw = two ? (pl.fast_k2_nw == 2 ? 4 : 8) : pl.fast_k2_nw;
         const int pm = h->cfg.pol_mode == 2 ? 2 : (h->cfg.pol_mode >= 4 ? 4 : 0);
-        snprintf(nm, sizeof nm, "frbch_k2_wave<%d,%d,%d,%d>", pl.fast_k2_log2m, nw, pm, two ? 2 : 1);
+        if (pl.fast_k2_log2m == 5) snprintf(nm, sizeof nm, "frbch_k2_wave<5,8,%d,4>", pm);
+        else snprintf(nm, sizeof nm, "frbch_k2_wave<%d,%d,%d,%d>", pl.fast_k2_log2m, nw, pm, two ? 2 : 1);
       } else {
         snprintf(nm, sizeof nm, "frbch_k2_fast<%d,%d>", pl.fast_k2_log2m, pl.fast_k2_nt);
       }

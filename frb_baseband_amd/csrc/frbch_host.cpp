@@ -238,7 +238,12 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
   }
   if (!(cfg.flags & 2u) && pl->c2 >= 256 && pl->c2 <= 8192 && pl->g >= 2 && !pl->coherent) {
     const int m = pl->c2 / 256;
-    const bool wave = want_wave && m <= 16 && !(cfg.flags & 4u);
+    // 2C = 8192 (M = 32): the wave kernel takes TWO time samples per workgroup (four waves and two virtual threads per lane
+    // each; persistent, the next tile prefetched into registers); one product and tscrunch <= 2 only -- everything else
+    // stays on the barrier kernels
+    const bool wave32 = m == 32 && pl->tscr <= 2 && pl->nif == 1 && !pl->fast_k1_wave && pl->fast_k1_log2m == 5 && pl->g == 2 &&
+                        !(cfg.flags & (1u << 21));
+    const bool wave = want_wave && (m <= 16 || wave32) && !(cfg.flags & 4u);
     const int tps = 16 * m;
     const int spw = tps < 64 ? 64 / tps : 1;
     // wave variant: 2 waves per workgroup (more, smaller workgroups resident per CU) when tscrunch
@@ -257,12 +262,12 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
     // 2C = 8192: one workgroup = 2 time samples (147 KB of LDS, one workgroup per CU), or -- no tscrunch -- ONE time
     // sample with 512 threads (74 KB: two workgroups per CU, one gathers while the other transforms)
     if (m == 32) pl->fast_k2_nt = (pl->tscr == 1 && !(cfg.flags & 4u)) ? 512 : 1024;
-    const int tt = wave ? nw * spw : pl->fast_k2_nt / tps;
+    const int tt = wave ? (m == 32 ? 2 : nw * spw) : pl->fast_k2_nt / tps;
     // 2C = 8192: a workgroup may walk tscrunch/tt tiles and add them up in registers
     const bool walk = m == 32 && pl->nif == 1 && pl->tscr > tt && pl->tscr % tt == 0 && pl->tscr <= (int)r;
-    const size_t seq = (size_t)pl->c2 + pl->c2 / 8 + (m == 32 ? 0 : 8);
+    const size_t seq = (size_t)pl->c2 + pl->c2 / 8 + ((m == 32 && !wave) ? 0 : 8);
     const size_t lds = (size_t)tt * seq * 8 + (walk ? (size_t)pl->c * 4 : 0) +   // + the row of sub-tile sums
-                       ((m == 32 && pl->fast_k2_nt == 512) ? 4096 : 0);         // + the radix-32 pass's twiddles (single-sample K2)
+                       ((m == 32 && (pl->fast_k2_nt == 512 || wave)) ? 4096 : 0);   // + the radix-32 pass's twiddles (single-sample K2)
     if (tt >= 1 && (pl->tscr <= tt || walk) && tt <= (int)r && (size_t)tt * pl->ncol * 4 <= lds && lds <= lds_limit &&
         (tt * pl->g) % 2 == 0 && (m > 1 || wave)) {   // 2C = 256 (radix 16 x 16): wave-private kernel only
       pl->fast_k2_log2m = ilog2(m);
@@ -292,9 +297,8 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
   }
   // chunks of eight time samples between the M = 32 barrier kernels (2 branches per K1 workgroup: the slab layout
   // leaves K2 one 32-byte piece per 128-KB slab)
-  if (!pl->fast_k1_wave && pl->fast_k1_log2m == 5 && !pl->fast_k2_wave && pl->fast_k2_log2m == 5 && !pl->coherent &&
-      !(cfg.flags & (1u << 21)))
-    pl->spill_tile_major = 8;
+  if (!pl->fast_k1_wave && pl->fast_k1_log2m == 5 && pl->fast_k2_log2m == 5 && !pl->coherent && !(cfg.flags & (1u << 21)))
+    pl->spill_tile_major = 8;   // (the wave K2 at 2C = 8192 reads this layout only: its plan condition above repeats these terms)
 
   // coherent pipeline on the register-pass kernels (barrier variants): K1 forward-only + K3 need R = 256*M, K2c needs
   // 2C = 256*M', M, M' in 2..32; the K1 group (64/M branches) becomes the layout group of the first spill

@@ -77,7 +77,11 @@ CASES = [
     (16.0, 256, 0.2, dict(dm=20.0, coherent=1, freq=600.0, pol=0, nbit=16)),     # M = 2 / 2
     (64.0, 4096, 1.1, dict(tscr=8)),                         # BASELINE config 4 shape (-t 8 -F4096:8192), 2 blocks: M = 32 barrier kernels, K2 walks 4 sub-tiles
     (64.0, 4096, 0.55, dict(tscr=8, flags=3)),                # the same through the generic kernels
-    (-64.0, 4096, 0.55, {}),                                  # M = 32, -t 1, LSB
+    (-64.0, 4096, 0.55, {}),                                  # M = 32, -t 1, LSB: wave K2 (frbch_k2_wave<5,8,2,4>, two time samples per workgroup, sums fused)
+    (64.0, 4096, 0.55, dict(tscr=2, nbit=-32)),               # the same with -t 2 (one output row per tile)
+    (64.0, 4096, 1.1, dict(pol=1, nbit=16)),                  # the same kernel family, single-product instantiation, 2 blocks, USB
+    (64.0, 4096, 0.55, dict(flags=1 << 20, nbit=2)),          # wave K2 with the separate statistics pass
+    (64.0, 4096, 0.55, dict(flags=8)),                        # -t 1 on the barrier K2 (frbch_k2_fast<5,512>)
     (64.0, 4096, 0.55, dict(flags=1 << 21, tscr=2)),          # M = 32 with the slab layout of the spill instead of chunks of eight time samples
     (64.0, 4096, 0.55, dict(pol=4, tscr=2, nbit=16)),         # M = 32, coherency products
     (64.0, 4096, 0.55, dict(pol=4, tscr=4)),                  # four products and tscrunch > 2: generic K2 behind the M = 32 K1
