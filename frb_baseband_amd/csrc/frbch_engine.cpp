@@ -313,7 +313,9 @@ void launch_k1_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
     if (p.stg) hipLaunchKernelGGL((fast::frbch_k1_wave<L, NWV, WPSV, true>), dim3(ngrp, ny), dim3(NTV), pl.k1_fast_lds, s, p);  \
     else hipLaunchKernelGGL((fast::frbch_k1_wave<L, NWV, WPSV, false>), dim3(ngrp, ny), dim3(NTV), pl.k1_fast_lds, s, p);        \
   } while (0)
-  if constexpr (LOG2M == 4) {
+  if constexpr (LOG2M == 5) {
+    FRBCH_K1W(5, 8, 4, 512);      // R = 8192: two branches per workgroup, four waves (two virtual threads per lane) each
+  } else if constexpr (LOG2M == 4) {
     FRBCH_K1W(4, 8, 2, 512);
   } else {
     if (LOG2M == 3 && pl.fast_k1_kind == 1) FRBCH_K1W(3, 4, 1, 256);
@@ -497,7 +499,7 @@ bool launch_k1_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
     set_fastdiv(q);
     if (h->stg_ready) q.stg = h->stg;   // launch_k0_stage has corner-turned this batch
     h->stg_ready = false;
-    q.tile_major = p.tile_major = pl.spill_tile_major == 2 ? 2 : 0;   // (K2 of this batch reads what this launch writes)
+    q.tile_major = p.tile_major = pl.spill_tile_major;   // 2 (R = 2048, paired branches) or 8 (R = 8192) or 0 (K2 of this batch reads what this launch writes)
     if (pl.fast_k1_split && q.stg) {    // persistent over blocks, one 16-wave workgroup per CU
       q.nblk = nb;
       const uint32_t ngrp = (uint32_t)(pl.c2 / 8);
@@ -512,6 +514,7 @@ bool launch_k1_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
       case 2: launch_k1_wave_t<2>(pl, q, nb, s); break;
       case 3: launch_k1_wave_t<3>(pl, q, nb, s); break;
       case 4: launch_k1_wave_t<4>(pl, q, nb, s); break;
+      case 5: launch_k1_wave_t<5>(pl, q, nb, s); break;
       default: return false;
     }
     return true;
@@ -673,6 +676,7 @@ int setup_fast(frbch_handle* h) {
       case 1: FRBCH_AL(1, 8, 1); break;
       case 2: FRBCH_AL(2, 8, 1); break;
       case 4: FRBCH_AL(4, 8, 2); break;
+      case 5: FRBCH_AL(5, 8, 4); break;
       default: FRBCH_AL(3, 8, 1); FRBCH_AL(3, 4, 1); FRBCH_AL(3, 8, 2); FRBCH_AL(3, 16, 2); break;
     }
 #undef FRBCH_AL
@@ -1148,7 +1152,7 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
   {
     char nm[64];
     if (pl.fast_k1_log2m && pl.fast_k1_wave) {
-      const int nw = pl.fast_k1_kind == 1 ? 4 : (pl.fast_k1_kind == 3 ? 16 : 8), wps = pl.fast_k1_kind >= 2 ? 2 : 1;   // kind 4: <4,8,2>
+      const int nw = pl.fast_k1_kind == 1 ? 4 : (pl.fast_k1_kind == 3 ? 16 : 8), wps = pl.fast_k1_kind == 5 ? 4 : (pl.fast_k1_kind >= 2 ? 2 : 1);   // kind 4: <4,8,2>, kind 5: <5,8,4>
       snprintf(nm, sizeof nm, "frbch_k1_wave<%d,%d,%d>", pl.fast_k1_log2m, nw, wps);
       h->kname[KID_K1] = nm;
     } else if (pl.fast_k1_log2m) {

@@ -203,9 +203,9 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
   const bool want_wave = !(cfg.flags & 8u);
   if (!(cfg.flags & 1u) && r >= 512 && r <= 8192 && in_bits == 2 && !pl->coherent) {   // the fast gather is written for 2-bit input
     const int m = (int)r / 256;
-    const bool wave = want_wave && m <= 16;
+    const bool wave = want_wave;               // (every M <= 32 has a wave-private K1; flags & 8 asks for the barrier kernels)
     const int tps = 16 * m;
-    const int gfast = wave ? (m == 16 ? 4 : 8 * (tps < 64 ? 64 / tps : 1)) : 64 / m;
+    const int gfast = wave ? (m == 32 ? 2 : (m == 16 ? 4 : 8 * (tps < 64 ? 64 / tps : 1))) : 64 / m;
     const size_t seq = (size_t)r + r / 8 + 8;
     // M = 8 experiments (flags & 64): two half-size workgroups per CU (4 branches each) filling interleaved
     // halves of the 8-branch layout rows, with 2 waves (or, flags & 128, 1 wave) per sequence
@@ -217,9 +217,11 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
       kind = 3;                                   // 16 waves, two per sequence, 8 branches
     } else if (wave && m == 16) {
       kind = 4;                                   // R = 4096: 8 waves, two per sequence, 4 branches
+    } else if (wave && m == 32) {
+      kind = 5;                                   // R = 8192: 8 waves, four per sequence (two virtual threads per lane), 2 branches
     }
     const size_t lds = (size_t)kg * seq * 8 + (size_t)r * (kg / 2) + 128 + (wave ? (size_t)kg * 132 : 0) +   // + unpack LUT + coarse delay factors + arrival counters
-                       ((m >= 16 && !wave) ? (size_t)m * 128 : 0);                                          // + the radix-M pass's twiddles (barrier kernels, M >= 16)
+                       ((m >= 16 && !wave) || m == 32 ? (size_t)m * 128 : 0);                               // + the radix-M pass's twiddles (barrier kernels, M >= 16; every kernel at M = 32)
     const size_t generic_lds = (size_t)gfast * seq1;   // fallback for unaligned calls keeps the layout
 #ifdef FRBCH_EXPERIMENTS
     static const int gl_env = getenv("FRBCH_GL") ? atoi(getenv("FRBCH_GL")) : 0;   // layout group = workgroup group
@@ -241,8 +243,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
     // 2C = 8192 (M = 32): the wave kernel takes TWO time samples per workgroup (four waves and two virtual threads per lane
     // each; persistent, the next tile prefetched into registers); one product and tscrunch <= 2 only -- everything else
     // stays on the barrier kernels
-    const bool wave32 = m == 32 && pl->tscr <= 2 && pl->nif == 1 && !pl->fast_k1_wave && pl->fast_k1_log2m == 5 && pl->g == 2 &&
-                        !(cfg.flags & (1u << 21));
+    const bool wave32 = m == 32 && pl->tscr <= 2 && pl->nif == 1 && pl->fast_k1_log2m == 5 && pl->g == 2 && !(cfg.flags & (1u << 21));
     const bool wave = want_wave && (m <= 16 || wave32) && !(cfg.flags & 4u);
     const int tps = 16 * m;
     const int spw = tps < 64 ? 64 / tps : 1;
@@ -297,7 +298,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
   }
   // chunks of eight time samples between the M = 32 barrier kernels (2 branches per K1 workgroup: the slab layout
   // leaves K2 one 32-byte piece per 128-KB slab)
-  if (!pl->fast_k1_wave && pl->fast_k1_log2m == 5 && pl->fast_k2_log2m == 5 && !pl->coherent && !(cfg.flags & (1u << 21)))
+  if (pl->fast_k1_log2m == 5 && pl->fast_k2_log2m == 5 && !pl->coherent && !(cfg.flags & (1u << 21)))
     pl->spill_tile_major = 8;   // (the wave K2 at 2C = 8192 reads this layout only: its plan condition above repeats these terms)
 
   // coherent pipeline on the register-pass kernels (barrier variants): K1 forward-only + K3 need R = 256*M, K2c needs
