@@ -1,10 +1,8 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "4096" > gpurun_out/k1w5_tests.log 2>&1
-echo "tests rc=$?"; tail -15 gpurun_out/k1w5_tests.log
-for a in "--nchan 4096 --bw 64 --seconds 5" "--nchan 4096 --bw 64 --seconds 5 --flags 8" ""; do
-python3 bench.py --no-cpu --no-host --no-traffic --steps 10 --warmup 5 $a 2>/dev/null | python3 -c "
-import json,sys
-j=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=j['roofline']['kernels_ms_per_step']
-print('$a', 'value', j['value'], {a:b for a,b in k.items() if b>0})"
-done
+mkdir -p /tmp/rx && cp -r include frb_baseband_amd /tmp/rx/ && make -C /tmp/rx/frb_baseband_amd/csrc clean >/dev/null && make -C /tmp/rx/frb_baseband_amd/csrc EXPERIMENTS=1 -j16 > gpurun_out/abl4_build.log 2>&1
+cp frb_baseband_amd/csrc/libfrbch.so /tmp/libfrbch_product.so
+cp /tmp/rx/frb_baseband_amd/csrc/libfrbch.so frb_baseband_amd/csrc/libfrbch.so || exit 1
+ARGS='--nchan 4096 --bw 64 --seconds 5' bash tools_ablate.sh cfg4 0 4096 16384 8192 20480 512 1024 1536 65536 > gpurun_out/abl4w.txt 2>&1
+cp /tmp/libfrbch_product.so frb_baseband_amd/csrc/libfrbch.so
+cat gpurun_out/abl4w.txt
