@@ -354,3 +354,21 @@ def test_dropped_and_invalid_frames(hip_lib, tmp_path, pol, via_file):
         c.run_file(vd, str(tmp_path / "inv.fil"))
         assert c.get_info().frames_invalid == 1 and c.get_info().frames_filled == 0
     pu.check_codes(ref2, open(str(tmp_path / "inv.fil"), "rb").read(), ocfg2)
+
+
+def test_invalid_frame_at_4096_channels(hip_lib):
+    """config-4 kernels, 2 blocks of 2^26 samples: block 0 is clean (wave K1 writes chunks of eight time samples, the wave
+    K2 reads 32-byte pieces of them), block 1 holds an invalid frame (generic K1 with the frame mask writes the slab
+    layout, the same wave K2 follows it)"""
+    raw = synth.make_vdif(1.1, bw_mhz=64.0, nchan=4096)
+    nfr = raw.size // 8032
+    fr = raw.reshape(nfr, 8032).copy()
+    fr[6000, 3] |= 0x80                                            # block 1 (frames 4194..8388)
+    inv = fr.reshape(-1)
+    ocfg = pu.oracle_cfg(64.0, 4096, 1.1)
+    ref = o.channelise(inv, ocfg)
+    assert ocfg.result["frame_counters"]["invalid"] == 1
+    with ch.Channeliser(pu.lib_cfg(hip_lib, 64.0, 4096, 1.1), hip_lib) as c:
+        got = c.channelise_bytes(inv)
+        assert c.get_info().frames_invalid == 1
+    pu.check_codes(ref, got, ocfg)
