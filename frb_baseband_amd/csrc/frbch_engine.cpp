@@ -903,7 +903,7 @@ int run_stats(frbch_handle* h, uint64_t rows, dev_stream_t s) {
     sp.offset = h->offset;
     sp.scale = h->scale;
     ProfScope ps(h, s, KID_STATS, (double)h->fused_chunks * pl.ncol * 16.0);
-    DEV_LAUNCH(frbch_stats_final, (int)pl.ncol, 1, 64, 64 * 2 * sizeof(double), s, sp);
+    DEV_LAUNCH(frbch_stats_final, (int)((pl.ncol + 7) / 8), 1, 256, 256 * 2 * sizeof(double), s, sp);
     CHECK_DEV(h, dev_check_launch(), "launch stats (final)");
     return FRBCH_OK;
   }
@@ -923,7 +923,7 @@ int run_stats(frbch_handle* h, uint64_t rows, dev_stream_t s) {
   const int gx4 = (int)((pl.ncol / 4 + 63) / 64);
   ProfScope ps(h, s, KID_STATS, (double)rows * pl.ncol * 4.0);
   DEV_LAUNCH(frbch_stats_partial, gx4, sp.nchunk, 64, 0, s, sp);
-  DEV_LAUNCH(frbch_stats_final, (int)pl.ncol, 1, 64, 64 * 2 * sizeof(double), s, sp);
+  DEV_LAUNCH(frbch_stats_final, (int)((pl.ncol + 7) / 8), 1, 256, 256 * 2 * sizeof(double), s, sp);
   (void)gx;
   CHECK_DEV(h, dev_check_launch(), "launch stats");
   return FRBCH_OK;
