@@ -75,6 +75,7 @@ struct frbch_handle {
   bool have_scale = false;     // offset/scale are defined
   bool scale_frozen = false;   // ... and stay as they are (set_rescale, -c after 1st interval, -I0)
   float* powbuf = nullptr;     // float power of the interval being measured [row][ncol]
+  float* scr2 = nullptr;       // two-stage tscrunch (Plan::k2_two_stage): [maxb][R/2][C] rows of two time samples
   uint64_t pow_cap_rows = 0, pow_rows = 0;
   double* partial = nullptr;
   int partial_chunks = 0;
@@ -342,7 +343,7 @@ int k2_wave_nt(const Plan& pl, uint32_t h_flags) {
 }
 // rows of partial sums the fused statistics use; 0 = this configuration cannot fuse (one column group per thread needed)
 int fused_stat_chunks(const Plan& pl, uint32_t h_flags, int pol_mode) {
-  if (pol_mode == 3) return 0;   // (PP+QQ)^2: its square overflows the fp32 partial sums (~1e24 squared)
+  if (pol_mode == 3 || pl.k2_two_stage) return 0;   // (two-stage tscrunch: K2 does not see the output rows)   // (PP+QQ)^2: its square overflows the fp32 partial sums (~1e24 squared)
   if (!(pl.fast_k2_log2m || pl.fast_k2_m1) || !pl.fast_k2_wave || pl.coherent || (h_flags & (1u << 20))) return 0;
   const int nt = k2_wave_nt(pl, h_flags), cg = (int)(pl.ncol / 4);
   if (cg > nt)   // a thread owns cg/nt column groups, one row of sums per workgroup (the MSTAT instantiations: 2C = 2048, two waves per sequence)
@@ -558,7 +559,25 @@ bool launch_k2_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
       case 2: launch_k2_wave_t<2>(pl, p, nb, s, h->cfg.flags); break;
       case 3: launch_k2_wave_t<3>(pl, p, nb, s, h->cfg.flags); break;
       case 4: launch_k2_wave_t<4>(pl, p, nb, s, h->cfg.flags); break;
-      case 5: launch_k2_wave_t<5>(pl, p, nb, s, h->cfg.flags); break;
+      case 5:
+        if (pl.k2_two_stage) {   // tscrunch > 2: rows of two time samples into the scratch buffer, then the sums
+          KParams q = p;
+          q.tscr = 2;
+          q.out_mode = FRBCH_OUT_FLOAT_POWER;
+          q.power_out = h->scr2;
+          q.row0 = 0;
+          q.stat_partial = nullptr;
+          launch_k2_wave_t<5>(pl, q, nb, s, h->cfg.flags);
+          p.scr_in = h->scr2;
+          p.scr_fact = (uint32_t)pl.k2_two_stage;
+          p.scr_rows = (uint64_t)nb * pl.rows_per_block;
+          p.stat_partial = nullptr;
+          const uint64_t groups = p.scr_rows * (uint64_t)(pl.c / 4);
+          hipLaunchKernelGGL(fast::frbch_k2_scrunch, dim3((unsigned)std::min<uint64_t>((groups + 255) / 256, 8192)), dim3(256), 0, s, p);
+        } else {
+          launch_k2_wave_t<5>(pl, p, nb, s, h->cfg.flags);
+        }
+        break;
       default: return false;
     }
     return true;
@@ -1179,6 +1198,10 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
   }
 
   CHECK_DEV(h, dev_malloc((void**)&h->spill, (size_t)pl.maxb * (pl.c2 / pl.g) * pl.gs * sizeof(cf)), "hipMalloc(spill)");
+#ifndef FRBCH_NO_FAST
+  if (pl.k2_two_stage)
+    CHECK_DEV(h, dev_malloc((void**)&h->scr2, (size_t)pl.maxb * (pl.r / 2) * pl.c * sizeof(float)), "hipMalloc(tscrunch scratch)");
+#endif
   CHECK_DEV(h, dev_malloc((void**)&h->s_dc, (size_t)pl.maxb * pl.c2 * sizeof(cf)), "hipMalloc(s_dc)");
   CHECK_DEV(h, dev_malloc((void**)&h->p0, (size_t)pl.maxb * pl.c2 * sizeof(cf)), "hipMalloc(p0)");
   if (pl.coherent) {
@@ -1211,7 +1234,7 @@ extern "C" void frbch_close(frbch_handle* h) {
   dev_free(h->ftw1_h); dev_free(h->ftw2_h);
   dev_free(h->ftw1_r); dev_free(h->ftw2_r); dev_free(h->ftw1_c); dev_free(h->ftw2_c); dev_free(h->td1); dev_free(h->td2);
   dev_free(h->spill); dev_free(h->s_dc); dev_free(h->p0);
-  dev_free(h->spill2); dev_free(h->chirp); dev_free(h->ptmp);
+  dev_free(h->spill2); dev_free(h->chirp); dev_free(h->ptmp); dev_free(h->scr2);
   dev_free(h->offset); dev_free(h->scale); dev_free(h->powbuf); dev_free(h->partial);
   dev_free(h->d_frames); dev_free(h->d_out); dev_free(h->stg); dev_free(h->d_fbad);
   for (int i = 0; i < 8; ++i) { dev_host_free(h->pin_in[i]); dev_host_free(h->pin_out[i]); }

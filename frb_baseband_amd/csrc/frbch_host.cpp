@@ -197,6 +197,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
   pl->fast_k1_log2m = pl->fast_k2_log2m = 0;
   pl->fast_k1_wave = pl->fast_k2_wave = 0;
   pl->fast_k2_m1 = 0;
+  pl->k2_two_stage = 0;
   pl->spill_tile_major = 0;
   pl->fast_k2_nt = (cfg.flags & 4u) ? 1024 : 512;
   pl->k1_fast_lds = pl->k2_fast_lds = 0;
@@ -243,7 +244,11 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
     // 2C = 8192 (M = 32): the wave kernel takes TWO time samples per workgroup (four waves and two virtual threads per lane
     // each; persistent, the next tile prefetched into registers); one product and tscrunch <= 2 only -- everything else
     // stays on the barrier kernels
-    const bool wave32 = m == 32 && pl->tscr <= 2 && pl->nif == 1 && pl->fast_k1_log2m == 5 && pl->g == 2 && !(cfg.flags & (1u << 21));
+    // tscrunch > 2: two stages -- the same kernel with two time samples per row into a scratch buffer, then frbch_k2_scrunch
+    // (K2 1.98 + 0.2 ms instead of the barrier kernel walking its sub-tiles, 3.85 ms at -t 8)
+    const bool wave32 = m == 32 && pl->nif == 1 && pl->fast_k1_log2m == 5 && pl->g == 2 && !(cfg.flags & (1u << 21)) &&
+                        (pl->tscr <= 2 || (pl->tscr % 2 == 0 && pl->tscr <= (int)r));
+    pl->k2_two_stage = (wave32 && want_wave && !(cfg.flags & 4u) && pl->tscr > 2) ? pl->tscr / 2 : 0;
     const bool wave = want_wave && (m <= 16 || wave32) && !(cfg.flags & 4u);
     const int tps = 16 * m;
     const int spw = tps < 64 ? 64 / tps : 1;
@@ -265,17 +270,18 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
     if (m == 32) pl->fast_k2_nt = (pl->tscr == 1 && !(cfg.flags & 4u)) ? 512 : 1024;
     const int tt = wave ? (m == 32 ? 2 : nw * spw) : pl->fast_k2_nt / tps;
     // 2C = 8192: a workgroup may walk tscrunch/tt tiles and add them up in registers
-    const bool walk = m == 32 && pl->nif == 1 && pl->tscr > tt && pl->tscr % tt == 0 && pl->tscr <= (int)r;
+    const bool walk = m == 32 && !wave && pl->nif == 1 && pl->tscr > tt && pl->tscr % tt == 0 && pl->tscr <= (int)r;
     const size_t seq = (size_t)pl->c2 + pl->c2 / 8 + ((m == 32 && !wave) ? 0 : 8);
     const size_t lds = (size_t)tt * seq * 8 + (walk ? (size_t)pl->c * 4 : 0) +   // + the row of sub-tile sums
                        ((m == 32 && (pl->fast_k2_nt == 512 || wave)) ? 4096 : 0);   // + the radix-32 pass's twiddles (single-sample K2)
-    if (tt >= 1 && (pl->tscr <= tt || walk) && tt <= (int)r && (size_t)tt * pl->ncol * 4 <= lds && lds <= lds_limit &&
+    if (tt >= 1 && (pl->tscr <= tt || walk || pl->k2_two_stage) && tt <= (int)r && (size_t)tt * pl->ncol * 4 <= lds && lds <= lds_limit &&
         (tt * pl->g) % 2 == 0 && (m > 1 || wave)) {   // 2C = 256 (radix 16 x 16): wave-private kernel only
       pl->fast_k2_log2m = ilog2(m);
       pl->fast_k2_m1 = m == 1;
       pl->fast_k2_wave = wave ? 1 : 0;
       pl->k2_fast_lds = lds;
     }
+    if (!(pl->fast_k2_wave && pl->fast_k2_log2m == 5)) pl->k2_two_stage = 0;
   }
 
   // R = 2048, flag bit 24: the split K1 (bin-parity halves, 16 independent waves per CU) instead of the paired-branch wave

@@ -74,6 +74,9 @@ struct KParams {
                             // fine bin j in the order the along-branch transform leaves it (S2_INDEX below)
   const cf* chirp;          // [2C/4][R][4]   Hermitian-extended dedispersion kernel, same order and layout
   float* ptmp;              // [nblk][nif][C][keep/T]  detected + scrunched power, channel-major
+  const float* scr_in;      // two-stage tscrunch (2C = 8192, tscrunch > 2): the wave K2's rows of two time samples each, [row][C] floats
+  uint32_t scr_fact;        // ... rows of scr_in per output row (tscrunch / 2)
+  uint64_t scr_rows;        // ... output rows of this launch
   double* stat_partial;     // fast K2, float power: [workgroup row][ncol][2] running (sum, sum of squares); null = off
   uint64_t stat_limit;      // ... of the rows below this absolute row of power_out (the end of the rescale interval)
   uint32_t nblk;            // blocks in this launch (persistent kernels loop over them)

@@ -75,7 +75,9 @@ CASES = [
     (-32.0, 1024, 0.3, dict(dm=56.7, coherent=1, freq=400.0, pol=4, tscr=2, flags=2)),  # register-pass K1 / K3 + generic K2c
     (32.0, 2048, 0.6, dict(dm=56.7, coherent=1, freq=1400.0, start=2 / 64e6)),  # -S off the K1 piece boundary: falls back to the generic K1 / K3, kernel table rebuilt
     (16.0, 256, 0.2, dict(dm=20.0, coherent=1, freq=600.0, pol=0, nbit=16)),     # M = 2 / 2
-    (64.0, 4096, 1.1, dict(tscr=8)),                         # BASELINE config 4 shape (-t 8 -F4096:8192), 2 blocks: M = 32 barrier kernels, K2 walks 4 sub-tiles
+    (64.0, 4096, 1.1, dict(tscr=8)),                         # BASELINE config 4 shape (-t 8 -F4096:8192), 2 blocks: M = 32 wave kernels, two-stage tscrunch (K2 rows of two samples + frbch_k2_scrunch)
+    (-64.0, 4096, 0.55, dict(tscr=4, nbit=2)),                # two-stage tscrunch, factor 2, 2-bit codes, LSB
+    (64.0, 4096, 0.55, dict(tscr=8, flags=8)),                # the barrier kernels: K2 (frbch_k2_fast<5,1024>) walks 4 sub-tiles
     (64.0, 4096, 0.55, dict(tscr=8, flags=3)),                # the same through the generic kernels
     (-64.0, 4096, 0.55, {}),                                  # M = 32, -t 1, LSB: wave K2 (frbch_k2_wave<5,8,2,4>, two time samples per workgroup, sums fused)
     (64.0, 4096, 0.55, dict(tscr=2, nbit=-32)),               # the same with -t 2 (one output row per tile)
