@@ -550,35 +550,35 @@ bool launch_k1_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
 bool launch_k2_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   const Plan& pl = h->pl;
   if (pl.fast_k2_wave) {
+    // tscrunch beyond the kernel's tile: rows of its largest tile into the scratch buffer (q), then the sums (p)
+    KParams q = p;
+    if (pl.k2_two_stage) {
+      q.tscr = pl.k2_stage1_tscr;
+      q.out_mode = FRBCH_OUT_FLOAT_POWER;
+      q.power_out = h->scr2;
+      q.row0 = 0;
+      q.stat_partial = nullptr;
+    }
+    KParams& k = pl.k2_two_stage ? q : p;
     switch (pl.fast_k2_log2m) {
       case 0:
         if (!pl.fast_k2_m1) return false;
-        launch_k2_wave_t<0>(pl, p, nb, s, h->cfg.flags);
+        launch_k2_wave_t<0>(pl, k, nb, s, h->cfg.flags);
         break;
-      case 1: launch_k2_wave_t<1>(pl, p, nb, s, h->cfg.flags); break;
-      case 2: launch_k2_wave_t<2>(pl, p, nb, s, h->cfg.flags); break;
-      case 3: launch_k2_wave_t<3>(pl, p, nb, s, h->cfg.flags); break;
-      case 4: launch_k2_wave_t<4>(pl, p, nb, s, h->cfg.flags); break;
-      case 5:
-        if (pl.k2_two_stage) {   // tscrunch > 2: rows of two time samples into the scratch buffer, then the sums
-          KParams q = p;
-          q.tscr = 2;
-          q.out_mode = FRBCH_OUT_FLOAT_POWER;
-          q.power_out = h->scr2;
-          q.row0 = 0;
-          q.stat_partial = nullptr;
-          launch_k2_wave_t<5>(pl, q, nb, s, h->cfg.flags);
-          p.scr_in = h->scr2;
-          p.scr_fact = (uint32_t)pl.k2_two_stage;
-          p.scr_rows = (uint64_t)nb * pl.rows_per_block;
-          p.stat_partial = nullptr;
-          const uint64_t groups = p.scr_rows * (uint64_t)(pl.c / 4);
-          hipLaunchKernelGGL(fast::frbch_k2_scrunch, dim3((unsigned)std::min<uint64_t>((groups + 255) / 256, 8192)), dim3(256), 0, s, p);
-        } else {
-          launch_k2_wave_t<5>(pl, p, nb, s, h->cfg.flags);
-        }
-        break;
+      case 1: launch_k2_wave_t<1>(pl, k, nb, s, h->cfg.flags); break;
+      case 2: launch_k2_wave_t<2>(pl, k, nb, s, h->cfg.flags); break;
+      case 3: launch_k2_wave_t<3>(pl, k, nb, s, h->cfg.flags); break;
+      case 4: launch_k2_wave_t<4>(pl, k, nb, s, h->cfg.flags); break;
+      case 5: launch_k2_wave_t<5>(pl, k, nb, s, h->cfg.flags); break;
       default: return false;
+    }
+    if (pl.k2_two_stage) {
+      p.scr_in = h->scr2;
+      p.scr_fact = (uint32_t)pl.k2_two_stage;
+      p.scr_rows = (uint64_t)nb * pl.rows_per_block;
+      p.stat_partial = nullptr;
+      const uint64_t groups = p.scr_rows * (uint64_t)(pl.ncol / 4);
+      hipLaunchKernelGGL(fast::frbch_k2_scrunch, dim3((unsigned)std::min<uint64_t>((groups + 255) / 256, 8192)), dim3(256), 0, s, p);
     }
     return true;
   }
@@ -1200,7 +1200,7 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
   CHECK_DEV(h, dev_malloc((void**)&h->spill, (size_t)pl.maxb * (pl.c2 / pl.g) * pl.gs * sizeof(cf)), "hipMalloc(spill)");
 #ifndef FRBCH_NO_FAST
   if (pl.k2_two_stage)
-    CHECK_DEV(h, dev_malloc((void**)&h->scr2, (size_t)pl.maxb * (pl.r / 2) * pl.c * sizeof(float)), "hipMalloc(tscrunch scratch)");
+    CHECK_DEV(h, dev_malloc((void**)&h->scr2, (size_t)pl.maxb * (pl.r / pl.k2_stage1_tscr) * pl.ncol * sizeof(float)), "hipMalloc(tscrunch scratch)");
 #endif
   CHECK_DEV(h, dev_malloc((void**)&h->s_dc, (size_t)pl.maxb * pl.c2 * sizeof(cf)), "hipMalloc(s_dc)");
   CHECK_DEV(h, dev_malloc((void**)&h->p0, (size_t)pl.maxb * pl.c2 * sizeof(cf)), "hipMalloc(p0)");

@@ -198,6 +198,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
   pl->fast_k1_wave = pl->fast_k2_wave = 0;
   pl->fast_k2_m1 = 0;
   pl->k2_two_stage = 0;
+  pl->k2_stage1_tscr = 0;
   pl->spill_tile_major = 0;
   pl->fast_k2_nt = (cfg.flags & 4u) ? 1024 : 512;
   pl->k1_fast_lds = pl->k2_fast_lds = 0;
@@ -249,9 +250,19 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
     const bool wave32 = m == 32 && pl->nif == 1 && pl->fast_k1_log2m == 5 && pl->g == 2 && !(cfg.flags & (1u << 21)) &&
                         (pl->tscr <= 2 || (pl->tscr % 2 == 0 && pl->tscr <= (int)r));
     pl->k2_two_stage = (wave32 && want_wave && !(cfg.flags & 4u) && pl->tscr > 2) ? pl->tscr / 2 : 0;
+    pl->k2_stage1_tscr = 2;
     const bool wave = want_wave && (m <= 16 || wave32) && !(cfg.flags & 4u);
     const int tps = 16 * m;
     const int spw = tps < 64 ? 64 / tps : 1;
+    // the same beyond the largest tile of the other wave K2s (8 sequences x spw; 4 at 2C = 4096): -t 16 at 1024 channels
+    // ran on the generic K2
+    {
+      const int tmax = m == 16 ? 4 : 8 * spw;
+      if (wave && m <= 16 && pl->tscr > tmax && pl->tscr % tmax == 0 && pl->tscr <= (int)r) {
+        pl->k2_two_stage = pl->tscr / tmax;
+        pl->k2_stage1_tscr = tmax;
+      }
+    }
     // wave variant: 2 waves per workgroup (more, smaller workgroups resident per CU) when tscrunch
     // allows it and flags & 16 does not ask for 4
     // sequences (time samples) per workgroup = nw*spw: the smallest of 2, 4, 8 (x spw) that holds one
@@ -281,7 +292,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
       pl->fast_k2_wave = wave ? 1 : 0;
       pl->k2_fast_lds = lds;
     }
-    if (!(pl->fast_k2_wave && pl->fast_k2_log2m == 5)) pl->k2_two_stage = 0;
+    if (!pl->fast_k2_wave || !(pl->fast_k2_log2m || pl->fast_k2_m1)) pl->k2_two_stage = 0;
   }
 
   // R = 2048, flag bit 24: the split K1 (bin-parity halves, 16 independent waves per CU) instead of the paired-branch wave

@@ -49,7 +49,11 @@ CASES = [
     (32.0, 1024, 0.14, dict(pol=0, nbit=2, tscr=4)),
     (32.0, 1024, 0.14, dict(tscr=8)),                        # -t 8: 8-sequence K2 workgroups
     (-32.0, 1024, 0.14, dict(pol=4, tscr=8, nbit=16)),
-    (32.0, 1024, 0.14, dict(tscr=16)),                       # -t 16: generic K2 behind the fast K1
+    (32.0, 1024, 0.14, dict(tscr=16)),                       # -t 16: two-stage tscrunch (wave K2 with its 8-sample tile + frbch_k2_scrunch x2)
+    (-32.0, 1024, 0.28, dict(tscr=32, pol=4, nbit=16)),      # the same x4 with four products
+    (64.0, 2048, 0.3, dict(tscr=8)),                         # 2C = 4096: 4-sample tile x2
+    (16.0, 128, 0.1, dict(tscr=64, nbit=2)),                 # 2C = 256 (four sequences per wave): 32-sample tile x2
+    (32.0, 1024, 0.14, dict(tscr=16, flags=2)),              # -t 16 on the generic K2
     (16.0, 512, 0.08, dict(tscr=8, pol=4)),
     (32.0, 1024, 0.14, dict(pol=1, nbit=16, interval=0.0)),
     (32.0, 1024, 0.14, dict(pol=3, interval=0.05, const=0)),
