@@ -907,6 +907,9 @@ int ensure_powbuf(frbch_handle* h) {
   return FRBCH_OK;
 }
 
+// threads per workgroup of frbch_stats_final (eight columns each): few columns = few workgroups, so more chunk lanes per column
+static int stat_final_threads(const Plan& pl) { return pl.ncol <= 512 ? 1024 : 256; }
+
 int run_stats(frbch_handle* h, uint64_t rows, dev_stream_t s) {
   const Plan& pl = h->pl;
   StatParams sp;
@@ -922,7 +925,7 @@ int run_stats(frbch_handle* h, uint64_t rows, dev_stream_t s) {
     sp.offset = h->offset;
     sp.scale = h->scale;
     ProfScope ps(h, s, KID_STATS, (double)h->fused_chunks * pl.ncol * 16.0);
-    DEV_LAUNCH(frbch_stats_final, (int)((pl.ncol + 7) / 8), 1, 256, 256 * 2 * sizeof(double), s, sp);
+    DEV_LAUNCH(frbch_stats_final, (int)((pl.ncol + 7) / 8), 1, stat_final_threads(pl), stat_final_threads(pl) * 2 * sizeof(double), s, sp);
     CHECK_DEV(h, dev_check_launch(), "launch stats (final)");
     return FRBCH_OK;
   }
@@ -942,7 +945,7 @@ int run_stats(frbch_handle* h, uint64_t rows, dev_stream_t s) {
   const int gx4 = (int)((pl.ncol / 4 + 63) / 64);
   ProfScope ps(h, s, KID_STATS, (double)rows * pl.ncol * 4.0);
   DEV_LAUNCH(frbch_stats_partial, gx4, sp.nchunk, 64, 0, s, sp);
-  DEV_LAUNCH(frbch_stats_final, (int)((pl.ncol + 7) / 8), 1, 256, 256 * 2 * sizeof(double), s, sp);
+  DEV_LAUNCH(frbch_stats_final, (int)((pl.ncol + 7) / 8), 1, stat_final_threads(pl), stat_final_threads(pl) * 2 * sizeof(double), s, sp);
   (void)gx;
   CHECK_DEV(h, dev_check_launch(), "launch stats");
   return FRBCH_OK;
