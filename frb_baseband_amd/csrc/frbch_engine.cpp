@@ -317,6 +317,10 @@ void launch_k1_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
   if constexpr (LOG2M == 5) {
     FRBCH_K1W(5, 8, 4, 512);      // R = 8192: two branches per workgroup, four waves (two virtual threads per lane) each
   } else if constexpr (LOG2M == 4) {
+    if (p.coherent) {   // forward transform + delay only, spectrum spilled (K2c follows)
+      if (p.stg) hipLaunchKernelGGL((fast::frbch_k1_wave<4, 8, 2, true, true>), dim3(ngrp, ny), dim3(512), pl.k1_fast_lds, s, p);
+      else hipLaunchKernelGGL((fast::frbch_k1_wave<4, 8, 2, false, true>), dim3(ngrp, ny), dim3(512), pl.k1_fast_lds, s, p);
+    } else
     FRBCH_K1W(4, 8, 2, 512);
   } else {
     if (LOG2M == 3 && pl.fast_k1_kind == 1) FRBCH_K1W(3, 4, 1, 256);
@@ -694,7 +698,11 @@ int setup_fast(frbch_handle* h) {
     if (pl.fast_k1_wave) switch (pl.fast_k1_log2m) {
       case 1: FRBCH_AL(1, 8, 1); break;
       case 2: FRBCH_AL(2, 8, 1); break;
-      case 4: FRBCH_AL(4, 8, 2); break;
+      case 4:
+        FRBCH_AL(4, 8, 2);
+        if (!rc) rc = allow_lds(h, fast::frbch_k1_wave<4, 8, 2, false, true>, pl.k1_fast_lds);
+        if (!rc) rc = allow_lds(h, fast::frbch_k1_wave<4, 8, 2, true, true>, pl.k1_fast_lds);
+        break;
       case 5: FRBCH_AL(5, 8, 4); break;
       default: FRBCH_AL(3, 8, 1); FRBCH_AL(3, 4, 1); FRBCH_AL(3, 8, 2); FRBCH_AL(3, 16, 2); break;
     }
@@ -907,8 +915,8 @@ int ensure_powbuf(frbch_handle* h) {
   return FRBCH_OK;
 }
 
-// threads per workgroup of frbch_stats_final (eight columns each): few columns = few workgroups, so more chunk lanes per column
-static int stat_final_threads(const Plan& pl) { return pl.ncol <= 512 ? 1024 : 256; }
+// columns per workgroup of frbch_stats_final: eight (whole lines), two when eight would leave fewer than 128 workgroups
+static int stat_final_cpw(const Plan& pl) { return pl.ncol < 1024 ? 2 : 8; }
 
 int run_stats(frbch_handle* h, uint64_t rows, dev_stream_t s) {
   const Plan& pl = h->pl;
@@ -922,10 +930,11 @@ int run_stats(frbch_handle* h, uint64_t rows, dev_stream_t s) {
     sp.nif = pl.nif;
     sp.flip = pl.flip;
     sp.nchunk = h->fused_chunks;
+    sp.cpw = stat_final_cpw(pl);
     sp.offset = h->offset;
     sp.scale = h->scale;
     ProfScope ps(h, s, KID_STATS, (double)h->fused_chunks * pl.ncol * 16.0);
-    DEV_LAUNCH(frbch_stats_final, (int)((pl.ncol + 7) / 8), 1, stat_final_threads(pl), stat_final_threads(pl) * 2 * sizeof(double), s, sp);
+    DEV_LAUNCH(frbch_stats_final, (int)((pl.ncol + sp.cpw - 1) / sp.cpw), 1, 256, 256 * 2 * sizeof(double), s, sp);
     CHECK_DEV(h, dev_check_launch(), "launch stats (final)");
     return FRBCH_OK;
   }
@@ -939,13 +948,14 @@ int run_stats(frbch_handle* h, uint64_t rows, dev_stream_t s) {
   sp.nchunk = (int)std::min<uint64_t>((uint64_t)h->partial_chunks, std::max<uint64_t>(1, rows / 32));
   sp.rows_per_chunk = (rows + sp.nchunk - 1) / sp.nchunk;
   sp.nchunk = (int)((rows + sp.rows_per_chunk - 1) / sp.rows_per_chunk);
+  sp.cpw = stat_final_cpw(pl);
   sp.offset = h->offset;
   sp.scale = h->scale;
   const int gx = (int)((pl.ncol + 255) / 256);
   const int gx4 = (int)((pl.ncol / 4 + 63) / 64);
   ProfScope ps(h, s, KID_STATS, (double)rows * pl.ncol * 4.0);
   DEV_LAUNCH(frbch_stats_partial, gx4, sp.nchunk, 64, 0, s, sp);
-  DEV_LAUNCH(frbch_stats_final, (int)((pl.ncol + 7) / 8), 1, stat_final_threads(pl), stat_final_threads(pl) * 2 * sizeof(double), s, sp);
+  DEV_LAUNCH(frbch_stats_final, (int)((pl.ncol + sp.cpw - 1) / sp.cpw), 1, 256, 256 * 2 * sizeof(double), s, sp);
   (void)gx;
   CHECK_DEV(h, dev_check_launch(), "launch stats");
   return FRBCH_OK;

@@ -344,6 +344,13 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
       pl->k1_lds = (size_t)gfast * seq1;
       pl->k1_fast_lds = lds1;
       pl->k3_fast_lds = lds3;
+      // R = 4096 (config 5): the wave K1 (8 waves, two per branch, 4 branches = the same layout group) in its forward-only form
+      const size_t ldsw = (size_t)gfast * seq * 8 + (size_t)r * (gfast / 2) + 128 + (size_t)gfast * 132;
+      if (m == 16 && want_wave && ldsw <= lds_limit) {
+        pl->fast_k1_wave = 1;
+        pl->fast_k1_kind = 4;
+        pl->k1_fast_lds = ldsw;
+      }
     }
   }
   if (pl->coherent && !(cfg.flags & 2u) && pl->c2 >= 512 && pl->c2 <= 8192 && pl->g >= 2) {

@@ -100,6 +100,7 @@ struct StatParams {
   uint64_t rows;            // rows that enter the statistics
   uint64_t rows_per_chunk;
   int ncol, c, nif, flip, nchunk;
+  int cpw;                  // frbch_stats_final: columns per workgroup (8 = whole lines of the partial sums; 2 when there are few columns)
   float* offset;            // [nif][C] input channel order
   float* scale;
 };
