@@ -54,6 +54,7 @@ CASES = [
     (64.0, 2048, 0.3, dict(tscr=8)),                         # 2C = 4096: 4-sample tile x2
     (16.0, 128, 0.1, dict(tscr=64, nbit=2)),                 # 2C = 256 (four sequences per wave): 32-sample tile x2
     (32.0, 1024, 0.14, dict(tscr=16, flags=2)),              # -t 16 on the generic K2
+    (32.0, 1024, 0.4, dict(tscr=16, maxb=1, interval=0.2)),  # two-stage tscrunch, one block per launch, the rescale interval ends inside the scan (float rows, then codes)
     (16.0, 512, 0.08, dict(tscr=8, pol=4)),
     (32.0, 1024, 0.14, dict(pol=1, nbit=16, interval=0.0)),
     (32.0, 1024, 0.14, dict(pol=3, interval=0.05, const=0)),
