@@ -621,6 +621,12 @@ bool launch_k3_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   const dim3 grid(pl.c / np, nb);
   if (pl.coh_nt == 512) {
     if (pl.coh_fast_r != 4) return false;
+    if (!(h->cfg.flags & 8u)) {   // wave form: persistent over the (block, channel) tiles, next tile prefetched piecewise
+      p.nblk = nb;
+      const uint64_t ntiles = (uint64_t)nb * pl.c;
+      hipLaunchKernelGGL((fast::frbch_k3_wave<4>), dim3((unsigned)std::min<uint64_t>(ntiles, 2048)), dim3(256), pl.k3_fast_lds, s, p);
+      return true;
+    }
     hipLaunchKernelGGL((fast::frbch_k3_fast<4, 512>), grid, dim3(512), pl.k3_fast_lds, s, p);
     return true;
   }
@@ -733,7 +739,10 @@ int setup_fast(frbch_handle* h) {
       case 1: rc = allow_lds(h, fast::frbch_k3_fast<1, 1024>, pl.k3_fast_lds); break;
       case 2: rc = allow_lds(h, fast::frbch_k3_fast<2, 1024>, pl.k3_fast_lds); break;
       case 3: rc = allow_lds(h, fast::frbch_k3_fast<3, 1024>, pl.k3_fast_lds); break;
-      case 4: rc = pl.coh_nt == 512 ? allow_lds(h, fast::frbch_k3_fast<4, 512>, pl.k3_fast_lds) : allow_lds(h, fast::frbch_k3_fast<4, 1024>, pl.k3_fast_lds); break;
+      case 4:
+        rc = pl.coh_nt == 512 ? allow_lds(h, fast::frbch_k3_fast<4, 512>, pl.k3_fast_lds) : allow_lds(h, fast::frbch_k3_fast<4, 1024>, pl.k3_fast_lds);
+        if (!rc && pl.coh_nt == 512) rc = allow_lds(h, fast::frbch_k3_wave<4>, pl.k3_fast_lds);
+        break;
       default: rc = allow_lds(h, fast::frbch_k3_fast<5, 1024>, pl.k3_fast_lds); break;
     }
     if (rc) return rc;
@@ -1225,7 +1234,7 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
     CHECK_DEV(h, dev_malloc((void**)&h->ptmp, (size_t)pl.maxb * pl.rows_per_block * pl.ncol * sizeof(float)), "hipMalloc(ptmp)");
     if ((rc = build_chirp(h, pl.coh_fast_r ? (1 << pl.coh_fast_r) : 0))) return rc;
     h->kname[KID_K2] = pl.coh_fast_c ? "frbch_k2c_fast" : "frbch_k2c_chirp";
-    if (pl.coh_fast_r) h->kname[KID_K3] = "frbch_k3_fast";
+    if (pl.coh_fast_r) h->kname[KID_K3] = (pl.coh_fast_r == 4 && pl.coh_nt == 512 && !(h->cfg.flags & 8u)) ? "frbch_k3_wave<4>" : "frbch_k3_fast";
   }
   CHECK_DEV(h, dev_malloc((void**)&h->offset, pl.ncol * sizeof(float)), "hipMalloc(offset)");
   CHECK_DEV(h, dev_malloc((void**)&h->scale, pl.ncol * sizeof(float)), "hipMalloc(scale)");
