@@ -346,8 +346,14 @@ int k2_wave_nt(const Plan& pl, uint32_t h_flags) {
   return pl.fast_k2_nw == 2 ? 128 : 256;
 }
 // rows of partial sums the fused statistics use; 0 = this configuration cannot fuse (one column group per thread needed)
+// the wave K3 (coherent filterbank, R = 4096) sums the statistics of its channel: one row of partial sums per persistent workgroup
+constexpr uint32_t kK3WaveWgs = 2048;
+bool k3_wave_planned(const Plan& pl, uint32_t h_flags) {
+  return pl.coherent && pl.coh_fast_r == 4 && pl.coh_nt == 512 && !(h_flags & 8u);
+}
 int fused_stat_chunks(const Plan& pl, uint32_t h_flags, int pol_mode) {
-  if (pol_mode == 3 || pl.k2_two_stage) return 0;   // (two-stage tscrunch: K2 does not see the output rows)   // (PP+QQ)^2: its square overflows the fp32 partial sums (~1e24 squared)
+  if (pol_mode == 3 || pl.k2_two_stage) return 0;   // (two-stage tscrunch: K2 does not see the output rows)
+  if (k3_wave_planned(pl, h_flags)) return (h_flags & (1u << 20)) ? 0 : (int)kK3WaveWgs;   // (PP+QQ)^2: its square overflows the fp32 partial sums (~1e24 squared)
   if (!(pl.fast_k2_log2m || pl.fast_k2_m1) || !pl.fast_k2_wave || pl.coherent || (h_flags & (1u << 20))) return 0;
   const int nt = k2_wave_nt(pl, h_flags), cg = (int)(pl.ncol / 4);
   if (cg > nt)   // a thread owns cg/nt column groups, one row of sums per workgroup (the MSTAT instantiations: 2C = 2048, two waves per sequence)
@@ -624,7 +630,7 @@ bool launch_k3_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
     if (!(h->cfg.flags & 8u)) {   // wave form: persistent over the (block, channel) tiles, next tile prefetched piecewise
       p.nblk = nb;
       const uint64_t ntiles = (uint64_t)nb * pl.c;
-      hipLaunchKernelGGL((fast::frbch_k3_wave<4>), dim3((unsigned)std::min<uint64_t>(ntiles, 2048)), dim3(256), pl.k3_fast_lds, s, p);
+      hipLaunchKernelGGL((fast::frbch_k3_wave<4>), dim3((unsigned)std::min<uint64_t>(ntiles, kK3WaveWgs)), dim3(256), pl.k3_fast_lds, s, p);
       return true;
     }
     hipLaunchKernelGGL((fast::frbch_k3_fast<4, 512>), grid, dim3(512), pl.k3_fast_lds, s, p);
@@ -884,7 +890,12 @@ int launch_back(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   const int tile_t = std::max(pl.tt, pl.tscr);
   const double out_b = p.out_mode == FRBCH_OUT_FLOAT_POWER ? (double)pl.ncol * 4.0 : (double)pl.row_bytes;
   const double bytes = (double)nb * ((double)pl.n * 8.0 + (double)pl.rows_per_block * out_b);
-  if (!((pl.fast_k2_log2m || pl.fast_k2_m1) && pl.fast_k2_wave) || pl.coherent) p.stat_partial = nullptr;   // only the wave-private K2 sums while it writes
+#ifndef FRBCH_NO_FAST
+  const bool k3_sums = k3_wave_planned(pl, h->cfg.flags) && h->coh_order_m != 0;   // (the generic K3 of a fallen-back launch does not sum)
+#else
+  const bool k3_sums = false;
+#endif
+  if ((!((pl.fast_k2_log2m || pl.fast_k2_m1) && pl.fast_k2_wave) || pl.coherent) && !k3_sums) p.stat_partial = nullptr;   // only the wave-private K2 / K3 sum while they write
   if (pl.coherent) {   // K2c (branches -> channels, x kernel), K3 (back to time, detect), K4 (time-major rows)
     {
       ProfScope ps(h, s, KID_K2, (double)nb * (double)pl.n * 24.0);
