@@ -909,6 +909,11 @@ int launch_back(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
       ProfScope ps(h, s, KID_K4, (double)nb * (double)pl.rows_per_block * (pl.ncol * 4.0 + out_b));
       const int tc = pl.ncol < 64 ? (int)pl.ncol : 64;
       const int gx = (int)((pl.rows_per_block + 63) / 64) * (int)(pl.ncol / tc);
+#ifndef FRBCH_NO_FAST
+      if (pl.ncol % 64 == 0 && pl.rows_per_block % 2 == 0 && pl.c % 4 == 0 && !(h->cfg.flags & 2u))   // (flags & 2: the generic back end)
+        hipLaunchKernelGGL(fast::frbch_k4_fast, dim3(gx, nb), dim3(256), 0, s, p);
+      else
+#endif
       DEV_LAUNCH(frbch_k4_out, gx, nb, pl.nthreads, pl.k4_lds, s, p);
     }
     CHECK_DEV(h, dev_check_launch(), "launch K2c/K3/K4");
@@ -1245,6 +1250,7 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
     CHECK_DEV(h, dev_malloc((void**)&h->ptmp, (size_t)pl.maxb * pl.rows_per_block * pl.ncol * sizeof(float)), "hipMalloc(ptmp)");
     if ((rc = build_chirp(h, pl.coh_fast_r ? (1 << pl.coh_fast_r) : 0))) return rc;
     h->kname[KID_K2] = pl.coh_fast_c ? "frbch_k2c_fast" : "frbch_k2c_chirp";
+    if (pl.ncol % 64 == 0 && pl.rows_per_block % 2 == 0 && pl.c % 4 == 0 && !(h->cfg.flags & 2u)) h->kname[KID_K4] = "frbch_k4_fast";
     if (pl.coh_fast_r) h->kname[KID_K3] = (pl.coh_fast_r == 4 && pl.coh_nt == 512 && !(h->cfg.flags & 8u)) ? "frbch_k3_wave<4>" : "frbch_k3_fast";
   }
   CHECK_DEV(h, dev_malloc((void**)&h->offset, pl.ncol * sizeof(float)), "hipMalloc(offset)");
