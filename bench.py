@@ -240,7 +240,7 @@ def collect_traffic(argv):
         if not m:
             continue
         short = (m.group(1) + (m.group(2) or "")).replace(" ", "")
-        short = re.sub(r",(true|false)>", ">", short)     # the engine's slot name carries no staging / statistics flag
+        short = re.sub(r"(,(true|false))+>", ">", short)  # the engine's slot name carries no staging / coherent / statistics flags
         nl = max(1, min(rec["n"].get("FETCH_SIZE", 1), rec["n"].get("WRITE_SIZE", 1)))
         corr = 2.0 if short.startswith(WIDE_FETCH) else 1.0
         out[short] = (rec["FETCH_SIZE"] / max(1, rec["n"].get("FETCH_SIZE", 1)) * corr +
