@@ -194,6 +194,17 @@ def launch_ranks(args, argv):
 WIDE_FETCH = ("frbch_k2_", "frbch_quantise", "frbch_stats_partial", "frbch_k0_stage", "frbch_k1_wave", "frbch_k1_split")
 
 
+def short_kernel_name(profiler_name):
+    """'void fast::frbch_k1_wave<3, 8, 1, true, false>(KParams)' -> 'frbch_k1_wave<3,8,1>': the name of the engine's timing
+    slot (frbch_get_timing), which carries no staging / coherent / statistics flags; None for other kernels"""
+    import re
+    m = re.search(r"(frbch_[a-z0-9_]+)(<[^>]*>)?", profiler_name)
+    if not m:
+        return None
+    short = (m.group(1) + (m.group(2) or "")).replace(" ", "")
+    return re.sub(r"(,(true|false))+>", ">", short)
+
+
 def collect_traffic(argv):
     """HBM bytes per launch of every frbch kernel, measured NOW: two child runs of this script under rocprofv3
     (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`: the counters do not fit one pass, MI355X_MICROARCH.md "rocprofv3 PMC slots").
@@ -234,13 +245,10 @@ def collect_traffic(argv):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     out = {"_source": "live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run (KB counters; wide fetches x2)"}
-    import re
     for k, rec in res.items():
-        m = re.search(r"(frbch_[a-z0-9_]+)(<[^>]*>)?", k)
-        if not m:
+        short = short_kernel_name(k)
+        if not short:
             continue
-        short = (m.group(1) + (m.group(2) or "")).replace(" ", "")
-        short = re.sub(r"(,(true|false))+>", ">", short)  # the engine's slot name carries no staging / coherent / statistics flags
         nl = max(1, min(rec["n"].get("FETCH_SIZE", 1), rec["n"].get("WRITE_SIZE", 1)))
         corr = 2.0 if short.startswith(WIDE_FETCH) else 1.0
         out[short] = (rec["FETCH_SIZE"] / max(1, rec["n"].get("FETCH_SIZE", 1)) * corr +

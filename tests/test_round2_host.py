@@ -210,3 +210,30 @@ def test_whole_file_path_with_a_mapped_output_equals_the_stream_path(emu_lib, tm
             c.reset()
             c.run_file(vd, out)                   # again into the existing file (O_TRUNC, then preallocated anew)
         assert open(out, "rb").read() == want
+
+
+def test_bench_maps_profiler_kernel_names_to_timing_slots():
+    import sys
+    """bench.py matches the rocprofv3 kernel names of its live PMC passes with the engine's timing-slot names
+    (frbch_get_timing): every trailing boolean template flag (staging, coherent, statistics) is dropped.  A kernel that
+    gains a flag must not silently turn `roofline.traffic` into null."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    try:
+        import bench
+    finally:
+        sys.path.remove(root)
+    cases = {
+        "void fast::frbch_k1_wave<3, 8, 1, true, false>(KParams)": "frbch_k1_wave<3,8,1>",
+        "void fast::frbch_k1_wave<4, 8, 2, false, true>(KParams)": "frbch_k1_wave<4,8,2>",
+        "void fast::frbch_k2_wave<3, 4, 2, 2, false>(KParams)": "frbch_k2_wave<3,4,2,2>",
+        "void fast::frbch_k2_wave<5, 8, 2, 4, true>(KParams)": "frbch_k2_wave<5,8,2,4>",
+        "void fast::frbch_k0_stage<4, true>(KParams)": "frbch_k0_stage<4>",
+        "void fast::frbch_k2_fast<5, 512>(KParams)": "frbch_k2_fast<5,512>",
+        "frbch_quantise": "frbch_quantise",
+        "void at::native::vectorized_elementwise_kernel<4>(int)": None,
+    }
+    for name, want in cases.items():
+        assert bench.short_kernel_name(name) == want, name
+    # the slot names of the engine for the headline workload, as bench.py looks them up
+    assert bench.short_kernel_name("void fast::frbch_k1_wave<3, 8, 1, true, false>(KParams)") in bench.VALU_PER_WAVE_BLOCK
