@@ -77,6 +77,8 @@ CASES = [
     (32.0, 2048, 0.6, dict(dm=56.7, coherent=1, freq=1400.0, freq_res=4096)),   # BASELINE config 5 shape: -F2048:4096 -D 56.7 -F2048:D (register-pass K1 / K2c / K3, M = 16)
     (32.0, 2048, 0.6, dict(dm=56.7, coherent=1, freq=1400.0, freq_res=4096, flags=3)),   # the same on the generic kernels
     (32.0, 2048, 0.6, dict(dm=56.7, coherent=1, freq=1400.0, freq_res=4096, flags=8)),   # the same with the barrier K1 (frbch_k1_fast<4>) instead of the forward-only wave K1
+    (-32.0, 2048, 0.6, dict(dm=56.7, coherent=1, freq=1400.0, freq_res=4096, pol=5, tscr=2, nbit=16)),   # wave K1 / K3 at R = 4096: four products (IQUV), -t 2, LSB, sums fused in K3
+    (32.0, 2048, 0.6, dict(dm=30.0, coherent=1, freq=1400.0, freq_res=4096, pol=0, tscr=4, nbit=2, interval=0.2)),   # ... one product, -t 4, 2-bit codes, the rescale interval ends inside the scan
     (-32.0, 1024, 0.3, dict(dm=56.7, coherent=1, freq=400.0, tscr=4, flags=1)),  # generic K1 / K3 (bit-reversed bins) + register-pass K2c
     (-32.0, 1024, 0.3, dict(dm=56.7, coherent=1, freq=400.0, pol=4, tscr=2, flags=2)),  # register-pass K1 / K3 + generic K2c
     (32.0, 2048, 0.6, dict(dm=56.7, coherent=1, freq=1400.0, start=2 / 64e6)),  # -S off the K1 piece boundary: falls back to the generic K1 / K3, kernel table rebuilt
