@@ -382,10 +382,13 @@ void launch_k2_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s, u
 #define FRBCH_K2W(NWV, PMV, GRID) hipLaunchKernelGGL((fast::frbch_k2_wave<LOG2M, NWV, PMV>), GRID, dim3(64 * NWV), pl.k2_fast_lds, s, p)
   if constexpr (LOG2M == 5) {   // 2C = 8192: two time samples per workgroup (32-byte pieces of the spill lines), four waves and two virtual threads per lane each; one workgroup per CU
     const dim3 grid1 = dim3(std::min<uint64_t>((uint64_t)(pl.r / 2) * nb, p.stat_partial ? 256u : 1024u));   // (multiples of 8: XCD-aware tile order)
-    // (the instantiation that keeps the rescale sums only while an interval is being measured)
-    if (pm == 2 && p.stat_partial) hipLaunchKernelGGL((fast::frbch_k2_wave<5, 8, 2, 4, true>), grid1, dim3(512), pl.k2_fast_lds, s, p);
+    // the instantiation with the per-thread column registers: the rescale sums while an interval is being measured, the
+    // frozen offset / scale when it digitises (loaded in the emit they wait for the whole prefetch: 2.28 vs 2.1 ms);
+    // the plain one for float rows without sums (two-stage tscrunch)
+    const bool cols = p.stat_partial || p.out_mode != FRBCH_OUT_FLOAT_POWER;
+    if (pm == 2 && cols) hipLaunchKernelGGL((fast::frbch_k2_wave<5, 8, 2, 4, true>), grid1, dim3(512), pl.k2_fast_lds, s, p);
     else if (pm == 2) hipLaunchKernelGGL((fast::frbch_k2_wave<5, 8, 2, 4>), grid1, dim3(512), pl.k2_fast_lds, s, p);
-    else if (p.stat_partial) hipLaunchKernelGGL((fast::frbch_k2_wave<5, 8, 0, 4, true>), grid1, dim3(512), pl.k2_fast_lds, s, p);
+    else if (cols) hipLaunchKernelGGL((fast::frbch_k2_wave<5, 8, 0, 4, true>), grid1, dim3(512), pl.k2_fast_lds, s, p);
     else hipLaunchKernelGGL((fast::frbch_k2_wave<5, 8, 0, 4>), grid1, dim3(512), pl.k2_fast_lds, s, p);
   } else
   if constexpr (LOG2M == 4) {   // 2C = 4096: two waves per sequence; 2 or 4 sequences per workgroup
