@@ -409,12 +409,12 @@ void launch_k2_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s, u
   if (LOG2M == 3 && !(h_flags & 32u)) {
     if (pl.fast_k2_nw == 2) {
       if (pm == 2) hipLaunchKernelGGL((fast::frbch_k2_wave<3, 4, 2, 2>), grid2, dim3(256), pl.k2_fast_lds, s, p);
-      else if (pm == 4 && p.stat_partial) hipLaunchKernelGGL((fast::frbch_k2_wave<3, 4, 4, 2, true>), grid2, dim3(256), pl.k2_fast_lds, s, p);
+      else if (pm == 4 && (p.stat_partial || p.out_mode != FRBCH_OUT_FLOAT_POWER)) hipLaunchKernelGGL((fast::frbch_k2_wave<3, 4, 4, 2, true>), grid2, dim3(256), pl.k2_fast_lds, s, p);
       else if (pm == 4) hipLaunchKernelGGL((fast::frbch_k2_wave<3, 4, 4, 2>), grid2, dim3(256), pl.k2_fast_lds, s, p);
       else hipLaunchKernelGGL((fast::frbch_k2_wave<3, 4, 0, 2>), grid2, dim3(256), pl.k2_fast_lds, s, p);
     } else {
       if (pm == 2) hipLaunchKernelGGL((fast::frbch_k2_wave<3, 8, 2, 2>), grid4, dim3(512), pl.k2_fast_lds, s, p);
-      else if (pm == 4 && p.stat_partial) hipLaunchKernelGGL((fast::frbch_k2_wave<3, 8, 4, 2, true>), grid4, dim3(512), pl.k2_fast_lds, s, p);
+      else if (pm == 4 && (p.stat_partial || p.out_mode != FRBCH_OUT_FLOAT_POWER)) hipLaunchKernelGGL((fast::frbch_k2_wave<3, 8, 4, 2, true>), grid4, dim3(512), pl.k2_fast_lds, s, p);
       else if (pm == 4) hipLaunchKernelGGL((fast::frbch_k2_wave<3, 8, 4, 2>), grid4, dim3(512), pl.k2_fast_lds, s, p);
       else hipLaunchKernelGGL((fast::frbch_k2_wave<3, 8, 0, 2>), grid4, dim3(512), pl.k2_fast_lds, s, p);
     }
