@@ -78,8 +78,8 @@ def synth_frames_device(torch, dev, seconds: float, bw_mhz: float, nchan: int, i
     return frames.reshape(-1), nfr
 
 
-def cpu_baseline(seconds_budget: float, bw: float, nchan: int):
-    """CPU restatement (oracle) timed on a bounded sample of the same workload; reported, not the target."""
+def cpu_baseline(seconds_budget: float, bw: float, nchan: int, pol: int = 2):
+    """CPU restatement (oracle) timed on a bounded sample of the same workload (same products); reported, not the target."""
     import numpy as np
     from frb_baseband_amd import synth
     from oracle import frb_oracle as o
@@ -94,18 +94,18 @@ def cpu_baseline(seconds_budget: float, bw: float, nchan: int):
         t0 = time.perf_counter()
         nblk = 0
         while time.perf_counter() - t0 < seconds_budget:
-            c_oracle.channelise_blocks(raw, bw, nchan, r, 2)
+            c_oracle.channelise_blocks(raw, bw, nchan, r, 2, pol)
             nblk += 2
         dt = time.perf_counter() - t0
         res = {"value": nblk * n / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
-               "sample": f"{nblk} filterbank blocks of {n} dual-pol samples, C fp32 port (oracle/frb_oracle.c), 1 thread"}
+               "sample": f"{nblk} filterbank blocks of {n} dual-pol samples of one IF, pol_mode {pol}, C fp32 port (oracle/frb_oracle.c), 1 thread"}
         # all host cores, the way the reference fans out: one single-threaded process per IF (base2fil.sh:60-66,219).
         # Child processes never touch the GPU.
         try:
             import subprocess
             # the GPU box gives a one-GPU job a share of 16 host cores: do not take more
             ncpu = min(len(os.sched_getaffinity(0)), int(os.environ.get("FRBCH_CPU_WORKERS", "16")))
-            procs = [subprocess.Popen([sys.executable, "-m", "oracle.c_oracle", str(seconds_budget / 2), str(bw), str(nchan), str(i)],
+            procs = [subprocess.Popen([sys.executable, "-m", "oracle.c_oracle", str(seconds_budget / 2), str(bw), str(nchan), str(i), str(pol)],
                                       cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
                      for i in range(ncpu)]
             rates = [float(pr.communicate(timeout=seconds_budget * 4 + 120)[0].strip().splitlines()[-1]) for pr in procs]
@@ -114,7 +114,7 @@ def cpu_baseline(seconds_budget: float, bw: float, nchan: int):
         except Exception as exc:   # reported baseline only: never fail the bench for it
             res["all_cores"] = {"error": str(exc)}
         return res
-    cfg = o.Config(bw_mhz=bw, nchan=nchan, total_s=10.0)
+    cfg = o.Config(bw_mhz=bw, nchan=nchan, total_s=10.0, pol_mode=pol)
     t0 = time.perf_counter()
     nblk = 0
     while time.perf_counter() - t0 < seconds_budget:
@@ -125,32 +125,63 @@ def cpu_baseline(seconds_budget: float, bw: float, nchan: int):
             "sample": f"{nblk} filterbank blocks of {n} dual-pol samples, numpy fp64 oracle (pocketfft), 1 thread"}
 
 
+# BASELINE.json configurations as workloads of this bench (per GPU).  `nif` IFs share the GPU: their rows land in ONE row buffer
+# [row][product][IF-major channels] through frbch_scan_device (the frequency concatenation of base2fil.sh:422 in the store addresses)
+WORKLOADS = {
+    # configs[2]: the largest single-GPU configuration = the default (golden argv process_vdif.py:166-171 `-d4 -F1024:2048`, IQUV
+    # formed from the four products as north_star says)
+    "cfg3": dict(nif=8, bw=32.0, nchan=1024, pol=5, tscrunch=1, seconds=10.0),
+    "cfg2": dict(nif=1, bw=32.0, nchan=1024, pol=2, tscrunch=1, seconds=10.0),                 # configs[1]
+    "cfg4": dict(nif=2, bw=64.0, nchan=4096, pol=2, tscrunch=8, seconds=10.0),                 # configs[3]: one GPU's share (2 IF)
+    "cfg5": dict(nif=1, bw=32.0, nchan=2048, pol=2, tscrunch=1, seconds=10.0, freq_res=4096, dm=56.7, coherent=True, freq=1400.0),
+    "cfg1": dict(nif=1, bw=16.0, nchan=128, pol=2, tscrunch=1, seconds=10.0),                  # configs[0] shape (parity case)
+}
+
+
 def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=10,
+    ap.add_argument("--warmup", type=int, default=5,
                     help="untimed steps; the first steps on a fresh box run ~5 %% slower (clock / power state settle)")
-    ap.add_argument("--seconds", type=float, default=10.0, help="seconds of one IF per step (SURVEY 8d: 10 s)")
-    ap.add_argument("--nchan", type=int, default=1024)
-    ap.add_argument("--bw", type=float, default=32.0)
-    ap.add_argument("--pol", type=int, default=2)
-    ap.add_argument("--tscrunch", type=int, default=1)
-    ap.add_argument("--dm", type=float, default=0.0)
-    ap.add_argument("--coherent", action="store_true", help="-F C:D: coherent dedispersion inside the filterbank (cfg 5)")
-    ap.add_argument("--freq", type=float, default=1608.0, help="centre sky frequency, MHz (matters with --coherent)")
-    ap.add_argument("--freq-res", type=int, default=0)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS), help="BASELINE configuration (default: configs[2])")
+    ap.add_argument("--nif", type=int, default=None, help="IFs per GPU (one handle each, one row buffer)")
+    ap.add_argument("--seconds", type=float, default=None, help="seconds of every IF per step (SURVEY 8d: 10 s)")
+    ap.add_argument("--nchan", type=int, default=None)
+    ap.add_argument("--bw", type=float, default=None)
+    ap.add_argument("--pol", type=int, default=None)
+    ap.add_argument("--tscrunch", type=int, default=None)
+    ap.add_argument("--dm", type=float, default=None)
+    ap.add_argument("--coherent", action="store_true", default=None, help="-F C:D: coherent dedispersion inside the filterbank (cfg 5)")
+    ap.add_argument("--freq", type=float, default=None, help="centre sky frequency, MHz (matters with --coherent)")
+    ap.add_argument("--freq-res", type=int, default=None)
     ap.add_argument("--maxb", type=int, default=0, help="filterbank blocks per kernel launch (0 = library default)")
+    ap.add_argument("--overlap", type=int, default=0, help="frbch_config.overlap: front-lane CUs | batches << 16 (0 = automatic, 1 = no overlap)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-host", action="store_true", help="skip the host-inclusive (frbch_run_file) leg")
-    ap.add_argument("--host-runs", type=int, default=3, help="timed frbch_run_file passes of the host-inclusive leg")
+    ap.add_argument("--no-host", action="store_true", help="skip the host-inclusive (frbch_run_file / frbch_run_scan) leg")
+    ap.add_argument("--host-runs", type=int, default=3, help="timed passes of the host-inclusive leg")
     ap.add_argument("--no-traffic", action="store_true", help="skip the live PMC passes (roofline.traffic = null)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short runs of the other BASELINE configurations")
+    ap.add_argument("--config-steps", type=int, default=5)
     ap.add_argument("--flags", type=int, default=0, help="kernel-selection flags of frbch_config (see include/frbch.h)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo with --share-gpu)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a one-GPU box: every rank uses cuda:0 (gloo)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # run under rocprofv3 by collect_traffic
     return ap
+
+
+def workload_spec(args, name=None):
+    """the workload's parameters, command-line values on top of the named configuration"""
+    spec = dict(nif=1, bw=32.0, nchan=1024, pol=2, tscrunch=1, seconds=10.0, freq_res=0, dm=0.0, coherent=False, freq=1608.0)
+    spec.update(WORKLOADS[name or args.workload])
+    if name is None:
+        for key, arg in (("nif", args.nif), ("bw", args.bw), ("nchan", args.nchan), ("pol", args.pol), ("tscrunch", args.tscrunch),
+                         ("seconds", args.seconds), ("freq_res", args.freq_res), ("dm", args.dm), ("coherent", args.coherent),
+                         ("freq", args.freq)):
+            if arg is not None:
+                spec[key] = arg
+    return spec
 
 
 def free_port():
@@ -260,45 +291,205 @@ def collect_traffic(argv):
 PCIE_PEAK_GBS = 64.0   # PCIe Gen5 x16, one direction (MI355X_MICROARCH.md host link)
 
 
-def host_inclusive(args, torch, dist, ch, cfg_kwargs, frames, nfr, rank, world, samples_per_step):
-    """What the reference's call does end to end (process_vdif.py:191 `digifil ... -o out hdr`): frbch_run_file from a
-    VDIF file to a .fil file, both on tmpfs -- disk excluded, PCIe both ways and the host threads included."""
+def budget_bytes_per_sample(spec):
+    """0.502 in + 8 + 8 spill + output bytes per dual-pol sample (8-bit codes: nprod / (2 T)); the coherent
+    path spills twice"""
+    nprod = 4 if spec["pol"] >= 4 else 1
+    return 0.502 + 16.0 * (2 if spec["coherent"] else 1) + nprod / (2.0 * spec["tscrunch"])
+
+
+class Workload:
+    """`nif` IFs of one BASELINE configuration on one GPU: handles, synthetic frames and the row buffer, all resident in HBM"""
+
+    def __init__(self, torch, dev, spec, args, local_rank, rank):
+        from frb_baseband_amd import channeliser as ch
+        self.torch, self.spec, self.ch = torch, spec, ch
+        nif = spec["nif"]
+        self.cfg_kwargs = []
+        self.chans = []
+        for i in range(nif):
+            # IF numbering and sidebands as base2fil.sh:30-67 (odd IFs LSB, even USB); rows in splice order: highest IF first
+            ifno = nif - i
+            kw = dict(bw_mhz=-spec["bw"] if ifno % 2 else spec["bw"], nchan=spec["nchan"], pol_mode=spec["pol"], nbit_out=8,
+                      tscrunch=spec["tscrunch"], rescale_constant=1, rescale_interval_s=10.0, total_s=spec["seconds"],
+                      device=local_rank, max_blocks_per_launch=args.maxb, flags=args.flags, dm=spec["dm"],
+                      coherent=1 if spec["coherent"] else 0, freq_mhz=spec["freq"], freq_res=spec["freq_res"], overlap=args.overlap)
+            if nif == 1:
+                kw["bw_mhz"] = spec["bw"]
+            self.cfg_kwargs.append(kw)
+            self.chans.append(ch.Channeliser(ch.new_config(**kw)))
+        self.info = self.chans[0].info
+        self.frames = []
+        for i in range(nif):
+            fr, self.nfr = synth_frames_device(torch, dev, spec["seconds"], spec["bw"], spec["nchan"], if_index=rank * nif + (nif - i))
+            self.frames.append(fr)
+        torch.cuda.synchronize()   # the library runs on its own streams: inputs must be complete
+        info = self.info
+        self.nblocks = (self.nfr * 8000 - info.block_payload_bytes) // info.block_stride_bytes + 1   # overlap-save when coherent
+        self.rows = self.nblocks * info.rows_per_block
+        self.row_pitch = nif * info.row_bytes
+        self.out = torch.empty(self.rows * self.row_pitch, dtype=torch.uint8, device=dev)
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.samples_per_step = nif * self.nblocks * info.block_stride_bytes * 2   # new dual-pol samples consumed (2-bit: 2 per byte)
+        self.ptrs = [f.data_ptr() for f in self.frames]
+
+    def scan(self, flush=True):
+        from frb_baseband_amd import multi_if
+        return multi_if.scan_device(self.chans, self.ptrs, self.nfr, 8032, 32, 0, self.nblocks, self.out.data_ptr(), self.rows,
+                                    flush=flush, stream=self.stream)
+
+    def step(self):
+        for c in self.chans:
+            c.reset()     # (waits for the previous step's work before it touches the rescale state)
+        return self.scan()
+
+    def timing(self):
+        """per-kernel device time, launches and algorithmic bytes summed over the IFs"""
+        agg = {}
+        for c in self.chans:
+            for k, v in c.get_timing().items():
+                a = agg.setdefault(k, {"launches": 0, "total_ms": 0.0, "algorithmic_bytes": 0.0})
+                for f in a:
+                    a[f] += v[f]
+        return agg
+
+    def measure(self, steps, warmup, dist=None):
+        torch = self.torch
+        for _ in range(warmup):
+            self.step()
+        torch.cuda.synchronize()
+        for c in self.chans:
+            c.set_profiling(True)
+            c.timing_reset()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            got = self.step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        assert got == self.rows, (got, self.rows)
+        return dt
+
+    def steady_state(self, steps):
+        """extra (not `value`): steady state of a long scan -- scale frozen after the first interval (-c), K2 digitises in-kernel"""
+        torch = self.torch
+        for c in self.chans:
+            c.set_profiling(False)
+            off, sc = c.get_rescale()
+            c.reset()
+            c.set_rescale(off, sc)
+        self.scan(flush=False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            self.scan(flush=False)
+        torch.cuda.synchronize()
+        return self.samples_per_step * steps / (time.perf_counter() - t1) / 1e6
+
+    def close(self):
+        for c in self.chans:
+            c.close()
+        self.chans = []
+        self.out = None
+        self.frames = []
+        self.torch.cuda.empty_cache()
+
+    def describe(self, world):
+        sp, info = self.spec, self.info
+        prod = {2: "Stokes-I", 4: "coherency (-d4)", 5: "full-Stokes IQUV (-d4 products -> I,Q,U,V)"}.get(sp["pol"], "pol%d" % sp["pol"])
+        dflag = {2: "-d1", 3: "-d3", 4: "-d4", 5: "-d4 -iquv"}.get(sp["pol"], "-P%d" % sp["pol"])
+        return (f"{sp['nif']} IF x {sp['bw']:g} MHz 2-bit dual-pol VDIF -> {sp['nchan']}-ch {prod} 8-bit .fil rows "
+                f"(per IF: -c -b8 {dflag}{' -t %d' % sp['tscrunch'] if sp['tscrunch'] > 1 else ''} -F{sp['nchan']}:{info.freq_res}"
+                f"{' -D %g -F%d:D' % (sp['dm'], sp['nchan']) if sp['coherent'] else ''}), {sp['seconds']:g} s per IF per step, "
+                f"{sp['nif']} IF per GPU on {world} GPU(s) (no data-path collective), one step = all IFs of the GPU into one "
+                f"[row][product][IF-major channel] row buffer (frbch_scan_device), first rescale interval measured every step, "
+                f"frames and rows resident in HBM")
+
+
+def roofline_of(timing, steps):
+    dom = max(timing.items(), key=lambda kv: kv[1]["total_ms"])
+    name, rec = dom
+    ach = rec["algorithmic_bytes"] / (rec["total_ms"] * 1e-3) / 1e9 if rec["total_ms"] > 0 else 0.0
+    return name, rec, ach
+
+
+def host_inclusive(args, torch, dist, wl, rank, world):
+    """What the reference's calls do end to end: VDIF files -> .fil, PCIe both ways and the host threads included; files on
+    tmpfs (disk excluded).  One IF through frbch_run_file (process_vdif.py:191 `digifil ... -o out hdr`), and -- when the GPU
+    holds several IFs -- the whole scan through frbch_run_scan (N digifil + N FIFOs + splice of base2fil.sh:348-350,404-448 in
+    one call) into /dev/null (a sink that does not copy: the library's own pipeline) ."""
+    ch = wl.ch
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
-    vd = os.path.join(base, f"frbch_bench_{os.getpid()}_if{rank}.vdif")
-    fil = vd.replace(".vdif", ".fil")
+    nif = wl.spec["nif"]
+    vds = [os.path.join(base, f"frbch_bench_{os.getpid()}_r{rank}_if{i}.vdif") for i in range(nif)]
+    fil = vds[0].replace(".vdif", ".fil")
+    res = {}
     try:
-        frames[: nfr * 8032].cpu().numpy().tofile(vd)
-        in_bytes = os.path.getsize(vd)
-        times = []
-        with ch.Channeliser(ch.new_config(**cfg_kwargs)) as c:
+        for i in range(nif):
+            wl.frames[i][: wl.nfr * 8032].cpu().numpy().tofile(vds[i])
+        in_bytes = os.path.getsize(vds[0])
+        per_if = wl.samples_per_step // nif
+
+        def timed(fn):
+            times = []
             for i in range(args.host_runs + 1):          # first pass untimed: pinned buffers, page cache, clocks
-                c.reset()
-                if os.path.exists(fil):
-                    os.remove(fil)        # what run_digifil does with --force before the call (process_vdif.py:146-149)
                 if dist is not None:
                     dist.barrier()
                 t0 = time.perf_counter()
-                c.run_file(vd, fil)
+                fn()
                 dt = time.perf_counter() - t0
                 if dist is not None:
-                    t = torch.tensor([dt], dtype=torch.float64, device=frames.device if args.backend == "nccl" else "cpu")
+                    t = torch.tensor([dt], dtype=torch.float64, device=wl.out.device if args.backend == "nccl" else "cpu")
                     dist.all_reduce(t, op=dist.ReduceOp.MAX)
                     dt = float(t.item())
                 if i:
                     times.append(dt)
+            return sorted(times)[len(times) // 2]
+
+        with ch.Channeliser(ch.new_config(**wl.cfg_kwargs[0])) as c:
+            def one():
+                c.reset()
+                if os.path.exists(fil):
+                    os.remove(fil)        # what run_digifil does with --force before the call (process_vdif.py:146-149)
+                c.run_file(vds[0], fil)
+            best = timed(one)
         out_bytes = os.path.getsize(fil)
-        best = sorted(times)[len(times) // 2]
         each_way = max(in_bytes, out_bytes) / best / 1e9
-        return {"value": round(samples_per_step * world / best / 1e6, 1), "unit": "Msamples/s", "s_per_scan": round(best, 4),
-                "realtime_x": round(samples_per_step / best / 1e6 / (2 * args.bw), 1),
-                "bytes_in_per_if": in_bytes, "bytes_out_per_if": out_bytes,
-                "pcie": {"bound": "pcie", "achieved": round(each_way, 2), "peak": PCIE_PEAK_GBS, "unit": "GB/s per direction per GPU",
-                         "frac": round(each_way / PCIE_PEAK_GBS, 4)},
-                "path": f"frbch_run_file: {base} VDIF -> pinned ring -> HBM -> pinned ring -> {base} .fil, median of {len(times)} scans after one untimed"}
+        res["run_file"] = {"value": round(per_if * world / best / 1e6, 1), "unit": "Msamples/s", "s_per_scan": round(best, 4),
+                           "realtime_x": round(per_if / best / 1e6 / (2 * wl.spec["bw"]), 1),
+                           "bytes_in_per_if": in_bytes, "bytes_out_per_if": out_bytes,
+                           "pcie": {"bound": "pcie", "achieved": round(each_way, 2), "peak": PCIE_PEAK_GBS, "unit": "GB/s per direction per GPU",
+                                    "frac": round(each_way / PCIE_PEAK_GBS, 4)},
+                           "path": f"frbch_run_file, one IF: {base} VDIF -> pinned ring -> HBM -> pinned ring -> {base} .fil, median of {args.host_runs} scans after one untimed"}
+        if nif > 1:
+            from frb_baseband_amd import multi_if
+            chans = [ch.Channeliser(ch.new_config(**kw)) for kw in wl.cfg_kwargs]
+            try:
+                def scan():
+                    for c in chans:
+                        c.reset()
+                    multi_if.run_scan(chans, vds, "/dev/null")
+                best = timed(scan)
+            finally:
+                for c in chans:
+                    c.close()
+            out_total = wl.rows * wl.row_pitch
+            each_way = max(in_bytes * nif, out_total) / best / 1e9
+            res["run_scan"] = {"value": round(wl.samples_per_step * world / best / 1e6, 1), "unit": "Msamples/s", "s_per_scan": round(best, 4),
+                               "bytes_in": in_bytes * nif, "bytes_out": out_total,
+                               "pcie": {"bound": "pcie", "achieved": round(each_way, 2), "peak": PCIE_PEAK_GBS,
+                                        "unit": "GB/s in the busier direction per GPU", "frac": round(each_way / PCIE_PEAK_GBS, 4)},
+                               "path": f"frbch_run_scan, {nif} IFs: {base} VDIF files -> pinned rings -> HBM (rows joined in the K2 / digitiser store addresses) -> pinned ring -> /dev/null"}
+        return res
     except Exception as exc:   # a reported extra: never fail the bench for it
-        return {"error": repr(exc)}
+        res["error"] = repr(exc)
+        return res
     finally:
-        for f in (vd, fil):
+        for f in vds + [fil]:
             try:
                 os.remove(f)
             except OSError:
@@ -316,13 +507,14 @@ def main():
     world = int(world_env or "1")
     if args.backend is None:
         args.backend = "gloo" if args.share_gpu else "nccl"
+    spec = workload_spec(args)
 
     # live PMC passes first: the children must start before this process initialises the GPU
     live_traffic = None
     if world == 1 and not args.no_traffic and not args.pmc_child:
-        live_traffic = collect_traffic(argv + ["--steps", "1", "--warmup", "1", "--no-cpu", "--no-host", "--no-traffic"])
+        live_traffic = collect_traffic(argv + ["--steps", "1", "--warmup", "1", "--no-cpu", "--no-host", "--no-traffic", "--no-configs"])
     if args.pmc_child:
-        args.steps, args.warmup, args.no_cpu, args.no_host = 1, 1, True, True
+        args.steps, args.warmup, args.no_cpu, args.no_host, args.no_configs = 1, 1, True, True, True
 
     import torch
     if world > 1:
@@ -340,45 +532,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from frb_baseband_amd import channeliser as ch
-    cfg_kwargs = dict(bw_mhz=args.bw, nchan=args.nchan, pol_mode=args.pol, nbit_out=8, tscrunch=args.tscrunch,
-                      rescale_constant=1, rescale_interval_s=10.0, total_s=args.seconds, device=local_rank,
-                      max_blocks_per_launch=args.maxb, flags=args.flags, dm=args.dm,
-                      coherent=1 if args.coherent else 0, freq_mhz=args.freq, freq_res=args.freq_res)
-    cfg = ch.new_config(**cfg_kwargs)
-    c = ch.Channeliser(cfg)
-    info = c.info
-    frames, nfr = synth_frames_device(torch, dev, args.seconds, args.bw, args.nchan, if_index=rank)
-    torch.cuda.synchronize()   # the library runs on its own stream: inputs must be complete
-    nblocks = (nfr * 8000 - info.block_payload_bytes) // info.block_stride_bytes + 1   # overlap-save when --coherent
-    rows = nblocks * info.rows_per_block
-    out = torch.empty(rows * info.row_bytes, dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    samples_per_step = nblocks * info.block_stride_bytes * 2      # new dual-pol samples consumed (2-bit: 2 per byte)
-
-    def step():
-        c.reset()     # (waits for the previous step's work on `stream` before it touches the rescale state)
-        r1 = c.process_device(frames.data_ptr(), nfr, 8032, 32, 0, nblocks, out.data_ptr(), out.numel(), stream)
-        r2 = c.flush_device(out.data_ptr() + r1 * info.row_bytes, out.numel() - r1 * info.row_bytes, stream)
-        return r1 + r2
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    c.set_profiling(True)
-    c.timing_reset()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        got_rows = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    assert got_rows == rows, (got_rows, rows)
-    dt_rank = dt
+    wl = Workload(torch, dev, spec, args, local_rank, rank)
+    dt = wl.measure(args.steps, args.warmup, dist)
     per_rank = None
     if dist is not None:
         red_dev = dev if args.backend == "nccl" else "cpu"
@@ -386,34 +541,47 @@ def main():
         dist.all_gather(tall, torch.tensor([dt], device=red_dev, dtype=torch.float64))
         per_rank = [float(t.item()) for t in tall]
         dt = max(per_rank)
-
-    timing = c.get_timing()
+    timing = wl.timing()
     if args.pmc_child:
-        c.close()
+        wl.close()
         return
-    # extra (not `value`): steady state of a long scan -- scale frozen after the first interval (-c), K2 digitises in-kernel
-    c.set_profiling(False)
-    off, sc = c.get_rescale()
-    c.reset()
-    c.set_rescale(off, sc)
-    c.process_device(frames.data_ptr(), nfr, 8032, 32, 0, nblocks, out.data_ptr(), out.numel(), stream)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        c.process_device(frames.data_ptr(), nfr, 8032, 32, 0, nblocks, out.data_ptr(), out.numel(), stream)
-    torch.cuda.synchronize()
-    steady = samples_per_step * args.steps / (time.perf_counter() - t1) / 1e6
-    c.close()
-    del out
+    steady = wl.steady_state(args.steps)
+    samples_per_step, nblocks, nif = wl.samples_per_step, wl.nblocks, spec["nif"]
+    workload_text = wl.describe(world)
     host = None
     if not args.no_host:
-        host = host_inclusive(args, torch, dist, ch, cfg_kwargs, frames, nfr, rank, world, samples_per_step)
+        host = host_inclusive(args, torch, dist, wl, rank, world)
+    wl.close()
+
+    # the other BASELINE configurations, short runs on this GPU (rank 0, N = 1): driver-visible, not `value`
+    configs = None
+    if world == 1 and not args.no_configs:
+        configs = {}
+        for name in ("cfg2", "cfg4", "cfg5"):
+            if name == args.workload:
+                continue
+            try:
+                sp = workload_spec(args, name)
+                w2 = Workload(torch, dev, sp, args, local_rank, rank)
+                d2 = w2.measure(args.config_steps, 3)
+                t2 = w2.timing()
+                st2 = w2.steady_state(args.config_steps)
+                v2 = w2.samples_per_step * args.config_steps / d2 / 1e6
+                nm, rec, ach = roofline_of(t2, args.config_steps)
+                bps = budget_bytes_per_sample(sp)
+                configs[name] = {"workload": w2.describe(1), "value": round(v2, 1), "unit": "Msamples/s", "steps": args.config_steps,
+                                 "ms_per_step": round(d2 / args.config_steps * 1e3, 4), "steady_state": round(st2, 1),
+                                 "dominant": nm, "frac": round(ach / HBM_PEAK_GBS, 4),
+                                 "whole_path_frac": round(v2 * 1e6 * bps / 1e9 / HBM_PEAK_GBS, 4),
+                                 "kernels_ms_per_step": {k: round(v["total_ms"] / args.config_steps, 4) for k, v in t2.items() if v["launches"]}}
+                w2.close()
+            except Exception as exc:   # reported extras: never fail the bench for them
+                configs[name] = {"error": repr(exc)}
+
     if rank == 0:
         total_samples = samples_per_step * args.steps * world
         value = total_samples / dt / 1e6
-        dom = max(timing.items(), key=lambda kv: kv[1]["total_ms"])
-        name, rec = dom
-        ach = rec["algorithmic_bytes"] / (rec["total_ms"] * 1e-3) / 1e9 if rec["total_ms"] > 0 else 0.0
+        name, rec, ach = roofline_of(timing, args.steps)
         # measured HBM bytes per launch of that kernel: live PMC passes of this run (collect_traffic), never a stored constant
         traffic = None
         if live_traffic and name in live_traffic:
@@ -421,41 +589,40 @@ def main():
         valu = None
         if name in VALU_PER_WAVE_BLOCK and rec["total_ms"] > 0:     # the other roof of this kernel: fp32 VALU lane operations
             per_wave, waves = VALU_PER_WAVE_BLOCK[name]
-            lane_ops = per_wave * waves * 64.0 * (2 * args.nchan // 8) * nblocks * rec["launches"]
+            lane_ops = per_wave * waves * 64.0 * (2 * spec["nchan"] // 8) * nblocks * nif * args.steps   # (every block of every IF and step once)
             tl = lane_ops / (rec["total_ms"] * 1e-3) / 1e12
             valu = {"bound": "valu", "achieved": round(tl, 2), "peak": VALU_PEAK_TLOPS, "unit": "T lane-ops/s (fp32, unpacked)",
                     "frac": round(tl / VALU_PEAK_TLOPS, 4), "instructions_per_wave_and_block": per_wave}
+        bps = budget_bytes_per_sample(spec)
         roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "traffic_source": (live_traffic or {}).get("_source"),
                 "avg_launch_ms": round(rec["total_ms"] / max(1, rec["launches"]), 5),
+                "launches_per_step": rec["launches"] / args.steps,
                 "algorithmic_bytes_per_launch": rec["algorithmic_bytes"] / max(1, rec["launches"]),
-                "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in timing.items()},
+                "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in timing.items() if v["launches"]},
+                "concurrency": "front stages (K0, K1, Kc) and back stages (K2, statistics, digitiser) run on two CU-masked streams "
+                               "and overlap: a kernel's launch duration is its time on ITS share of the CUs, the sum over kernels exceeds ms_per_step",
                 "valu": valu,
-                "whole_path": {"algorithmic_bytes_per_sample": 17.0 if args.pol < 4 else 18.5,
-                               "achieved": round(value / world * 1e6 * (17.0 if args.pol < 4 else 18.5) / 1e9, 1),
-                               "frac": round(value / world * 1e6 * (17.0 if args.pol < 4 else 18.5) / 1e9 / HBM_PEAK_GBS, 4)}}
-        prod = {2: "Stokes-I", 4: "coherency (-d4)", 5: "IQUV"}.get(args.pol, "pol%d" % args.pol)
-        dflag = {2: "-d1", 3: "-d3", 4: "-d4", 5: "-d4 -iquv"}.get(args.pol, "-P%d" % args.pol)
+                "whole_path": {"algorithmic_bytes_per_sample": round(bps, 3),
+                               "achieved": round(value / world * 1e6 * bps / 1e9, 1),
+                               "frac": round(value / world * 1e6 * bps / 1e9 / HBM_PEAK_GBS, 4)}}
         line = {
             "metric": "Msamples/s channelised to .fil per GPU; achieved HBM GB/s vs peak",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{world} IF x {args.bw:g} MHz 2-bit dual-pol VDIF -> {args.nchan}-ch "
-                                   f"{prod} 8-bit .fil "
-                                   f"(-c -b8 {dflag}{' -t %d' % args.tscrunch if args.tscrunch > 1 else ''} -F{args.nchan}:{info.freq_res}"
-                                   f"{' -D %g -F%d:D' % (args.dm, args.nchan) if args.coherent else ''}), {args.seconds:g} s per IF per step, "
-                                   f"one IF per GPU (no data-path collective), first rescale interval measured every step, frames and .fil rows resident in HBM",
-                       "samples_per_step_per_gpu": samples_per_step, "blocks_per_step": nblocks,
-                       "realtime_x": round(value / world / (2 * args.bw), 2),
+            "config": {"workload": workload_text, "baseline_config": args.workload,
+                       "samples_per_step_per_gpu": samples_per_step, "blocks_per_step_per_if": nblocks, "ifs_per_gpu": nif,
+                       "realtime_x": round(value / world / (2 * spec["bw"] * nif), 2),
                        "steady_state_msamples_per_gpu": round(steady, 1),
                        "per_rank_seconds": per_rank},
             "roofline": roof,
             "host_inclusive": host,
+            "configs": configs,
         }
         if world == 1 and not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.bw, args.nchan)
+            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds, spec["bw"], spec["nchan"], spec["pol"])
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

@@ -9,9 +9,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libfrbch.so")
+# FRBCH_LIB: another build of the same library for this process (the profiling build `make exp`); default: the product
+LIB_PATH = os.environ.get("FRBCH_LIB") or os.path.join(_HERE, "csrc", "libfrbch.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK, E_ARG, E_IO, E_FORMAT, E_DEVICE, E_NOMEM, E_STATE, E_CAPACITY = 0, -1, -2, -3, -4, -5, -6, -7
 
@@ -28,7 +29,7 @@ class FrbchConfig(C.Structure):
         ("max_blocks_per_launch", C.c_uint32), ("flags", C.c_uint32),
         ("telescope", C.c_char * 64), ("source", C.c_char * 64),
         ("ra", C.c_char * 32), ("dec", C.c_char * 32), ("datafile", C.c_char * 512),
-        ("input_bits", C.c_uint32), ("reserved1", C.c_uint32),
+        ("input_bits", C.c_uint32), ("overlap", C.c_uint32),
         ("levels", C.c_float * 4),
     ]
 
@@ -82,6 +83,8 @@ SYMBOLS = {
     "frbch_reset": (C.c_int, [_P]),
     "frbch_run_file": (C.c_int, [_P, C.c_char_p, C.c_char_p]),
     "frbch_run_scan": (C.c_int, [C.POINTER(_P), C.c_uint32, C.POINTER(C.c_char_p), C.c_char_p]),
+    "frbch_scan_device": (C.c_int, [C.POINTER(_P), C.c_uint32, C.POINTER(_P), C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint64,
+                                    C.c_uint64, C.c_int, _P, C.c_size_t, C.c_uint64, C.POINTER(C.c_uint64), _P]),
     "frbch_push": (C.c_int, [_P, _P, C.c_size_t]),
     "frbch_flush": (C.c_int, [_P]),
     "frbch_pull": (C.c_long, [_P, _P, C.c_size_t]),

@@ -94,6 +94,17 @@ static inline int dev_memset32(void* d, uint32_t v, size_t nwords, dev_stream_t 
 static inline int dev_sync(dev_stream_t s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
 static inline int dev_stream_create(dev_stream_t* s) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking) == hipSuccess ? 0 : -1; }
 static inline void dev_stream_destroy(dev_stream_t s) { (void)hipStreamDestroy(s); }
+// a stream whose kernels run only on the compute units whose bit is set in `mask` (bit i: XCD i % 8)
+static inline int dev_stream_create_masked(dev_stream_t* s, const uint32_t* mask, uint32_t words) {
+  return hipExtStreamCreateWithCUMask(s, words, mask) == hipSuccess ? 0 : -1;
+}
+static inline int dev_cu_count(int d) {
+  int n = 0;
+  return hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess ? n : 0;
+}
+// ordering-only events (no timestamps) and cross-stream waits
+static inline int dev_event_create_sync(hipEvent_t* e) { return hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess ? 0 : -1; }
+static inline int dev_stream_wait(dev_stream_t s, hipEvent_t e) { return hipStreamWaitEvent(s, e, 0) == hipSuccess ? 0 : -1; }
 static inline int dev_check_launch() { return hipGetLastError() == hipSuccess ? 0 : -1; }
 static inline int dev_host_alloc(void** p, size_t n) { return hipHostMalloc(p, n, hipHostMallocDefault) == hipSuccess ? 0 : -1; }
 static inline void dev_host_free(void* p) { if (p) (void)hipHostFree(p); }

@@ -116,6 +116,21 @@ struct frbch_handle {
   size_t sink_line_pitch = 0;      // bytes per (row, product) line of the shared buffer
   uint64_t sink_rows = 0, sink_rows_cap = 0;
 
+  // rows for a wider row buffer: values between consecutive (row, product) lines of code_out (0 = nchan: packed rows)
+  uint64_t out_pitch = 0;
+  // two-lane pipeline: spill regions in flight, ordering events
+  uint8_t* stg_cur = nullptr;      // staged payload of the launch in progress (stg + region offset)
+  int lane_cus = 0;                // compute units of the stream the next K1 goes to (0 = all of them)
+  dev_event_t region_ev[8];        // recorded behind the last back stage that read spill region r
+  bool region_busy[8] = {false, false, false, false, false, false, false, false};
+  bool region_ev_made = false;
+  std::vector<dev_event_t> evpool; // ordering events, used round-robin
+  size_t evnext = 0;
+  uint32_t next_region = 0;        // spill region of the next batch
+  dev_event_t quant_ev{};          // behind a digitiser that ran on the back lane (mode 2)
+  bool quant_ev_made = false, quant_busy = false;
+  int quant_lane_cus = 0;          // CUs of the lane the digitiser was sent to
+
   // profiling
   bool profiling = false;
   std::vector<EventPair> events;
@@ -249,6 +264,7 @@ KParams base_params(const frbch_handle* h) {
   p.digi_mean = pl.digi_mean;
   p.digi_scale = pl.digi_scale;
   p.digi_max = pl.digi_max;
+  p.out_pitch = h->out_pitch ? h->out_pitch : (uint64_t)pl.c;
 #ifdef FRBCH_EXPERIMENTS
   p.dbg = (h->cfg.flags >> 8) & 0xFFFu;   // bits 8..19: timing-only ablations (wrong output)
 #else
@@ -270,7 +286,7 @@ void launch_k1_fast_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
   hipLaunchKernelGGL(fast::frbch_k1_fast<LOG2M>, dim3(pl.c2 / pl.g, nb), dim3(1024), pl.k1_fast_lds, s, p);
 }
 template <int LOG2M>
-void launch_k1_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
+void launch_k1_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s, int ncu) {
   // persistent over blocks: the resident workgroups each keep their branch group and loop over the batch
   p.nblk = nb;
 #ifdef FRBCH_EXPERIMENTS
@@ -307,8 +323,16 @@ void launch_k1_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
 #else
   const uint32_t cap_env = 0u;
 #endif
-  const uint32_t resident = cap_env ? cap_env : 256u * (uint32_t)std::max<size_t>(1, (160 * 1024) / pl.k1_fast_lds);
+  const uint32_t resident = cap_env ? cap_env : (uint32_t)(ncu > 0 ? ncu : 256) * (uint32_t)std::max<size_t>(1, (160 * 1024) / pl.k1_fast_lds);
   uint32_t ny = std::max<uint32_t>(1, std::min<uint32_t>(nb, resident / std::max<uint32_t>(1, ngrp)));
+  if (ngrp > resident && ngrp % resident != 0) {
+    // more branch groups than resident workgroups and not a whole number of rounds (a CU-masked lane, e.g. 256 groups on
+    // 160 CUs): split the blocks over ny workgroups per group so that ngrp * ny fills whole rounds
+    uint32_t g = ngrp, r = resident;
+    while (r) { const uint32_t t = g % r; g = r; r = t; }
+    const uint32_t want = resident / g;
+    if (want <= nb) ny = want;
+  }
 #define FRBCH_K1W(L, NWV, WPSV, NTV)                                                                                       \
   do {                                                                                                                  \
     if (p.stg) hipLaunchKernelGGL((fast::frbch_k1_wave<L, NWV, WPSV, true>), dim3(ngrp, ny), dim3(NTV), pl.k1_fast_lds, s, p);  \
@@ -478,7 +502,7 @@ void launch_k0_stage(frbch_handle* h, const KParams& p, uint32_t nb, dev_stream_
   q.frames = p.frames + fr0 * p.frame_bytes;
   q.rel0 = (uint32_t)rel0;
   set_fastdiv(q);
-  q.stg_out = h->stg;
+  q.stg_out = h->stg_cur ? h->stg_cur : h->stg;
   ProfScope ps(h, s, KID_K0, (double)nb * (double)pl.block_payload_bytes * (1.0 + (double)p.frame_bytes / p.payload_bytes));
   const dim3 grid((pl.r / 64) * (pl.c / 256), nb);
   const bool wide = !(rel0 % 16 || p.payload_bytes % 16 || p.header_bytes % 16 || p.frame_bytes % 16);
@@ -511,7 +535,7 @@ bool launch_k1_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
     q.frames = p.frames + fr0 * p.frame_bytes;
     q.rel0 = (uint32_t)rel0;
     set_fastdiv(q);
-    if (h->stg_ready) q.stg = h->stg;   // launch_k0_stage has corner-turned this batch
+    if (h->stg_ready) q.stg = h->stg_cur ? h->stg_cur : h->stg;   // launch_k0_stage has corner-turned this batch
     h->stg_ready = false;
     q.tile_major = p.tile_major = pl.spill_tile_major;   // 2 (R = 2048, paired branches) or 8 (R = 8192) or 0 (K2 of this batch reads what this launch writes)
     if (pl.fast_k1_split && q.stg) {    // persistent over blocks, one 16-wave workgroup per CU
@@ -524,18 +548,18 @@ bool launch_k1_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
     }
     if (pl.fast_k1_split) h->kname[KID_K1] = "frbch_k1_wave<3,8,1>";
     switch (pl.fast_k1_log2m) {
-      case 1: launch_k1_wave_t<1>(pl, q, nb, s); break;
-      case 2: launch_k1_wave_t<2>(pl, q, nb, s); break;
-      case 3: launch_k1_wave_t<3>(pl, q, nb, s); break;
-      case 4: launch_k1_wave_t<4>(pl, q, nb, s); break;
-      case 5: launch_k1_wave_t<5>(pl, q, nb, s); break;
+      case 1: launch_k1_wave_t<1>(pl, q, nb, s, h->lane_cus); break;
+      case 2: launch_k1_wave_t<2>(pl, q, nb, s, h->lane_cus); break;
+      case 3: launch_k1_wave_t<3>(pl, q, nb, s, h->lane_cus); break;
+      case 4: launch_k1_wave_t<4>(pl, q, nb, s, h->lane_cus); break;
+      case 5: launch_k1_wave_t<5>(pl, q, nb, s, h->lane_cus); break;
       default: return false;
     }
     return true;
   }
   p.tile_major = pl.spill_tile_major == 8 ? 8 : 0;   // (K2 of this batch reads what this launch writes)
   KParams q = p;
-  if (h->stg_ready) q.stg = h->stg;   // launch_k0_stage has corner-turned this batch
+  if (h->stg_ready) q.stg = h->stg_cur ? h->stg_cur : h->stg;   // launch_k0_stage has corner-turned this batch
   h->stg_ready = false;
   {   // launch-relative 32-bit addressing where the batch fits (else the kernel divides in 64 bits)
     const uint64_t fr0 = p.payload_off / p.payload_bytes;
@@ -854,13 +878,21 @@ int build_chirp(frbch_handle* h, int order_m) {
   return FRBCH_OK;
 }
 
-// K1 + Kc over nb blocks: frames -> spill, P0
-int launch_front(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
+dev_event_t pool_event(frbch_handle* h);
+// K0 + K1 + Kc over nb blocks: frames -> spill, P0.  K0 may run on another stream (`sk`, the back lane's CUs): K1 waits for it.
+int launch_front(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s, dev_stream_t sk) {
   const Plan& pl = h->pl;
   p.tile_major = 0;   // set by the K1 that writes that layout
   {
     const bool masked = p.fbad != nullptr;   // blocks that touch invalid / filler frames: the generic K1 zeroes those samples
-    if (!masked) launch_k0_stage(h, p, nb, s);
+    if (!masked) {
+      launch_k0_stage(h, p, nb, sk);
+      if (sk != s && h->stg_ready) {
+        const dev_event_t e = pool_event(h);
+        dev_event_record(e, sk);
+        (void)dev_stream_wait(s, e);
+      }
+    }
     const double bytes = (double)nb * ((double)pl.block_payload_bytes * p.frame_bytes / p.payload_bytes +
                                        (double)pl.n * 8.0 + (double)pl.c2 * 8.0);
     ProfScope ps(h, s, KID_K1, bytes);
@@ -989,7 +1021,7 @@ int run_stats(frbch_handle* h, uint64_t rows, dev_stream_t s) {
   return FRBCH_OK;
 }
 
-int run_quantise(frbch_handle* h, uint64_t rows, uint8_t* dst, dev_stream_t s) {
+int run_quantise(frbch_handle* h, uint64_t rows, uint8_t* dst, dev_stream_t s, int ncu = 0) {
   const Plan& pl = h->pl;
   QuantParams qp;
   memset(&qp, 0, sizeof qp);
@@ -1007,29 +1039,62 @@ int run_quantise(frbch_handle* h, uint64_t rows, uint8_t* dst, dev_stream_t s) {
   qp.digi_scale = pl.digi_scale;
   qp.digi_max = pl.digi_max;
   const uint64_t total = rows * pl.ncol / 4;
-  const uint64_t gx = std::min<uint64_t>((total + 256 * 4 - 1) / (256 * 4), 256 * 32);   // grid-stride, 4 groups per thread per trip
+  // grid-stride, 4 groups per thread per trip, up to 32 workgroups per CU of the stream it runs on.  (A bare 16-B-in / 4-B-out
+  // stream reads fastest with 8 waves per CU, tools/micro/stream_cus; this kernel carries ~60 VALU instructions per group --
+  // index arithmetic, rescale, four digitiser chains -- and needs the waves: 1 / 2 / 4 / 8 / 32 workgroups per CU measured
+  // 2.8 / 1.76 / 1.41 / 1.59 / 1.28 ms per 6.4 GB, profiles/r03_overlap_sweep_quantise_lane.txt)
+#ifdef FRBCH_EXPERIMENTS
+  static const int wgs_env = getenv("FRBCH_QUANT_WGS") ? atoi(getenv("FRBCH_QUANT_WGS")) : 0;
+#else
+  const int wgs_env = 0;
+#endif
+  const uint64_t gx = std::min<uint64_t>((total + 256 * 4 - 1) / (256 * 4), (uint64_t)(ncu > 0 ? ncu : 256) * (uint64_t)(wgs_env > 0 ? wgs_env : 32));
   qp.grid_x = (uint32_t)std::max<uint64_t>(1, gx);
   qp.log2_c = 0;
   while ((1 << qp.log2_c) < pl.c) ++qp.log2_c;
+  qp.log2_ncol = 0;
+  while ((1ull << qp.log2_ncol) < pl.ncol) ++qp.log2_ncol;
+  qp.pitch = h->out_pitch ? h->out_pitch : (uint64_t)pl.c;
   ProfScope ps(h, s, KID_QUANT, (double)rows * (pl.ncol * 4.0 + pl.row_bytes));
   DEV_LAUNCH(frbch_quantise, qp.grid_x, 1, 256, 0, s, qp);
   CHECK_DEV(h, dev_check_launch(), "launch quantise");
   return FRBCH_OK;
 }
 
+// bytes between the starts of consecutive output rows at d_out, and bytes `rows` rows span from d_out
+// (packed rows, or this IF's columns of a wider row buffer: out_pitch values per (row, product) line)
+uint64_t out_row_span(const frbch_handle* h) {
+  const Plan& pl = h->pl;
+  if (!h->out_pitch) return pl.row_bytes;
+  const uint64_t bits = pl.row_bytes * 8 / pl.ncol;                 // bits per value
+  return h->out_pitch * (uint64_t)pl.nif * bits / 8;
+}
+uint64_t out_extent(const frbch_handle* h, uint64_t rows) {
+  const Plan& pl = h->pl;
+  if (!rows) return 0;
+  if (!h->out_pitch) return rows * pl.row_bytes;
+  const uint64_t bits = pl.row_bytes * 8 / pl.ncol;                 // bits per value
+  const uint64_t line = h->out_pitch * bits / 8, seg = (uint64_t)pl.c * bits / 8;
+  return (rows * pl.nif - 1) * line + seg;
+}
+
 // Close the rescale interval that sits at the front of powbuf: statistics over `stat_rows` rows,
 // then digitise `emit_rows` rows into dst and keep the rest for the next interval.
+struct Chain;
+dev_stream_t chain_quant_stream(Chain* c, dev_stream_t s, int* ncu);
+void chain_quant_done(Chain* c, dev_stream_t sq);
 int finalize_interval(frbch_handle* h, uint64_t stat_rows, uint8_t* d_out, size_t cap, uint64_t* rows_written,
-                      dev_stream_t s) {
+                      dev_stream_t s0, Chain* ch = nullptr) {
   const Plan& pl = h->pl;
-  int rc = run_stats(h, stat_rows, s);
+  int rc = run_stats(h, stat_rows, s0);
   if (rc) return rc;
+  const dev_stream_t s = chain_quant_stream(ch, s0, &h->quant_lane_cus);   // (the back lane when the digitiser can run beside the next K1)
   h->have_scale = true;
   if (h->cfg.rescale_constant) h->scale_frozen = true;
   const uint64_t emit_rows = h->scale_frozen ? h->pow_rows : stat_rows;
-  if ((*rows_written + emit_rows) * pl.row_bytes > cap)
+  if (out_extent(h, *rows_written + emit_rows) > cap)
     return fail(h, FRBCH_E_CAPACITY, "output buffer too small for the rows of a completed rescale interval");
-  rc = run_quantise(h, emit_rows, d_out + *rows_written * pl.row_bytes, s);
+  rc = run_quantise(h, emit_rows, d_out + *rows_written * out_row_span(h), s, s != s0 ? h->quant_lane_cus : 0);
   if (rc) return rc;
   *rows_written += emit_rows;
   h->rows_out += emit_rows;
@@ -1045,27 +1110,249 @@ int finalize_interval(frbch_handle* h, uint64_t stat_rows, uint8_t* d_out, size_
   h->pow_rows = rest;
   h->fused_rows = 0;
   h->fused_valid = false;   // (re-armed when an interval starts on an empty buffer)
+  if (s != s0) {            // later work of this handle on the power buffer / the codes is ordered behind the digitiser
+    if (!h->quant_ev_made) { (void)dev_event_create_sync(&h->quant_ev); h->quant_ev_made = true; }
+    dev_event_record(h->quant_ev, s);
+    h->quant_busy = true;
+    chain_quant_done(ch, s);
+  }
   return FRBCH_OK;
 }
 
 bool fused_ok(const frbch_handle* h) { return h->scale_frozen; }
 
+// =============================================================================================
+// Two lanes.  The front half of a batch (K0, K1, Kc) is bound by the instruction chain of its
+// waves and leaves HBM more than half idle; the back half (K2, statistics, digitiser) is bound by HBM and leaves the
+// vector units idle.  They run on two streams whose CU masks split the chip, so that the front of batch b + 1 overlaps the
+// back of batch b.  Mask bit i is CU i / 8 of XCD i % 8 (the driver deals the bits round-robin over the XCDs): a lane of
+// the first 8 k bits owns k CUs of every XCD, and the workgroup -> XCD round-robin the kernels' tile orders rely on holds
+// inside a lane as on the whole chip.  Placement affects speed only: every dependency is a stream-ordered event.
+// =============================================================================================
+struct Lanes {
+  dev_stream_t f = 0, b = 0, b2 = 0;   // front lane; back lane; a second stream on the back lane's CUs (K0 beside K2)
+  int ncu = 0, ncu_f = 0;
+  bool ok = false;
+};
+std::mutex g_lanes_mutex;
+std::vector<std::pair<std::pair<int, int>, Lanes*>> g_lanes;   // (device, front CUs) -> lanes; live until the process ends
+
+Lanes* get_lanes(int device, int ncu_front) {
+  std::lock_guard<std::mutex> lk(g_lanes_mutex);
+  for (auto& e : g_lanes)
+    if (e.first.first == device && e.first.second == ncu_front) return e.second->ok ? e.second : nullptr;
+  Lanes* ln = new Lanes();
+  g_lanes.push_back({{device, ncu_front}, ln});
+  ln->ncu = dev_cu_count(device);
+  if (ln->ncu < 32 || ln->ncu % 8 || ncu_front < 8 || ncu_front > ln->ncu - 8 || ncu_front % 8) return nullptr;
+  const uint32_t words = (uint32_t)((ln->ncu + 31) / 32);
+  std::vector<uint32_t> mf(words, 0u), mb(words, 0u);
+  for (int i = 0; i < ln->ncu; ++i) (i < ncu_front ? mf : mb)[(size_t)i >> 5] |= 1u << (i & 31);
+  if (dev_stream_create_masked(&ln->f, mf.data(), words) != 0 || dev_stream_create_masked(&ln->b, mb.data(), words) != 0 ||
+      dev_stream_create_masked(&ln->b2, mb.data(), words) != 0) {
+    (void)dev_last_error_string();
+    return nullptr;
+  }
+  ln->ncu_f = ncu_front;
+  ln->ok = true;
+  return ln;
+}
+
+dev_event_t pool_event(frbch_handle* h) {
+  if (h->evpool.empty()) {
+    h->evpool.resize(64);
+    for (auto& e : h->evpool) (void)dev_event_create_sync(&e);
+  }
+  const dev_event_t e = h->evpool[h->evnext];
+  h->evnext = (h->evnext + 1) % h->evpool.size();
+  return e;
+}
+
+// The stages of one API call (or of one scan call, across its IFs) in the order they are queued.
+struct Chain {
+  Lanes* ln = nullptr;            // null: every stage on `user`, as queued
+  dev_stream_t user = 0;
+  frbch_handle* owner = nullptr;  // whose event pool is used
+  uint32_t stages_total = 0;      // (front, back) pairs the chain will run; the last back stage runs on the whole chip
+  uint32_t fronts = 0, backs = 0;
+  bool k0_back = false;           // K0 beside the back lane's kernels instead of in front of K1 on the front lane
+  int mode = 1;                   // 1: K2 / statistics / digitiser on the back lane, K0 / K1 / Kc on the front lane
+                                  // 2: only the digitiser of a completed interval on the (small) back lane, beside the NEXT
+                                  //    front stage on the front lane; K2 keeps the whole chip
+  dev_event_t ev_entry{}, ev_front{}, ev_back{}, ev_q{};
+  dev_stream_t s_front = 0, s_back = 0;   // streams of the last front / back stage queued
+  bool f_rooted = false, b_rooted = false, b2_rooted = false;
+  bool q_pending = false, have_q = false; // mode 2: a digitiser runs on the back lane (the next front stage goes beside it)
+};
+
+void chain_begin(Chain* c, frbch_handle* owner, dev_stream_t user, Lanes* ln, uint32_t stages_total, bool k0_back, int mode) {
+  *c = Chain();
+  c->owner = owner;
+  c->user = user;
+  c->ln = stages_total >= 2 ? ln : nullptr;
+  c->stages_total = stages_total;
+  c->mode = mode;
+  c->k0_back = k0_back && mode == 1;
+  if (c->ln) {
+    c->ev_entry = pool_event(owner);
+    dev_event_record(c->ev_entry, user);
+  }
+}
+// stream of the next front stage: the first one has the chip to itself (nothing to overlap with yet)
+dev_stream_t chain_front_stream(Chain* c) {
+  if (!c->ln || c->fronts == 0) return c->user;
+  if (c->mode == 2) {
+    if (!c->q_pending) return c->user;
+    c->q_pending = false;
+    if (!c->f_rooted) {
+      (void)dev_stream_wait(c->ln->f, c->ev_entry);
+      c->f_rooted = true;
+    }
+    if (c->backs) (void)dev_stream_wait(c->ln->f, c->ev_back);   // the K2 before it had the whole chip
+    return c->ln->f;
+  }
+  if (!c->f_rooted) {
+    (void)dev_stream_wait(c->ln->f, c->ev_entry);
+    if (c->s_front == c->user && c->fronts) (void)dev_stream_wait(c->ln->f, c->ev_front);   // behind the whole-chip first front
+    c->f_rooted = true;
+  }
+  return c->ln->f;
+}
+dev_stream_t chain_k0_stream(Chain* c, dev_stream_t front) {
+  if (!c->ln || !c->k0_back || front == c->user) return front;
+  if (!c->b2_rooted) {
+    (void)dev_stream_wait(c->ln->b2, c->ev_entry);
+    c->b2_rooted = true;
+  }
+  return c->ln->b2;
+}
+void chain_front_done(Chain* c, dev_stream_t sf) {
+  c->s_front = sf;
+  c->fronts++;
+  if (c->ln) {
+    c->ev_front = pool_event(c->owner);
+    dev_event_record(c->ev_front, sf);
+  }
+}
+// stream of the next back stage (ordered behind its front stage and the previous back stage)
+dev_stream_t chain_back_stream(Chain* c) {
+  if (!c->ln) return c->user;
+  if (c->mode == 2) {
+    if (c->s_front != c->user) (void)dev_stream_wait(c->user, c->ev_front);
+    return c->user;
+  }
+  const bool last = c->backs + 1 >= c->stages_total;
+  const dev_stream_t sb = last ? c->user : c->ln->b;
+  if (sb == c->ln->b && !c->b_rooted) {
+    (void)dev_stream_wait(sb, c->ev_entry);
+    c->b_rooted = true;
+  }
+  if (c->s_front != sb) (void)dev_stream_wait(sb, c->ev_front);
+  if (c->backs && c->s_back != sb) (void)dev_stream_wait(sb, c->ev_back);
+  return sb;
+}
+void chain_back_done(Chain* c, dev_stream_t sb) {
+  c->s_back = sb;
+  c->backs++;
+  if (c->ln) {
+    c->ev_back = pool_event(c->owner);
+    dev_event_record(c->ev_back, sb);
+  }
+}
+// everything the chain queued is ordered in front of what follows on the caller's stream
+// mode 2: the stream the digitiser of a completed interval goes to -- the back lane while another front stage is still to
+// come (it runs beside that stage's K1), else the stream `s` of the statistics in front of it
+dev_stream_t chain_quant_stream(Chain* c, dev_stream_t s, int* ncu) {
+  if (!c || !c->ln || c->mode != 2 || c->fronts >= c->stages_total) return s;
+  const dev_stream_t sq = c->ln->b;
+  *ncu = c->ln->ncu - c->ln->ncu_f;
+  if (!c->b_rooted) {
+    (void)dev_stream_wait(sq, c->ev_entry);
+    c->b_rooted = true;
+  }
+  const dev_event_t e = pool_event(c->owner);
+  dev_event_record(e, s);               // behind the statistics
+  (void)dev_stream_wait(sq, e);
+  return sq;
+}
+void chain_quant_done(Chain* c, dev_stream_t sq) {
+  if (!c || !c->ln || c->mode != 2 || sq != c->ln->b) return;
+  c->ev_q = pool_event(c->owner);
+  dev_event_record(c->ev_q, sq);
+  c->q_pending = true;
+  c->have_q = true;
+}
+void chain_end(Chain* c) {
+  if (!c->ln) return;
+  if (c->have_q) (void)dev_stream_wait(c->user, c->ev_q);
+  if (c->fronts && c->s_front != c->user) (void)dev_stream_wait(c->user, c->ev_front);
+  if (c->backs && c->s_back != c->user) (void)dev_stream_wait(c->user, c->ev_back);
+  // (every K0 on the second back-lane stream was waited for by its K1, whose back stage is ordered above)
+}
+// more work was queued on the stream of the last back stage (the digitiser of a flushed interval): later stages and the
+// end of the chain are ordered behind it
+void chain_back_touch(Chain* c) {
+  if (!c->ln || !c->backs) return;
+  c->ev_back = pool_event(c->owner);
+  dev_event_record(c->ev_back, c->s_back);
+}
+
+// front CUs / batches per call requested through frbch_config::overlap (0 = automatic)
+int overlap_front_cus(const frbch_handle* h) {
+  const uint32_t v = h->cfg.overlap & 0xFFFFu;
+#ifdef FRBCH_EXPERIMENTS
+  static const int env = getenv("FRBCH_FRONT_CUS") ? atoi(getenv("FRBCH_FRONT_CUS")) : -1;
+  if (env >= 0) return env;
+#endif
+  if (v == 1) return 0;                       // overlap off
+  if (v) return (int)(v / 8 * 8);
+  // automatic = no overlap.  Measured (profiles/r03_overlap_sweep_*.txt): K1 AND K2 both scale with
+  // their share of the CUs (K2 on 96 CUs takes 2.4x its whole-chip time: it is bound by its waves' chains, not by HBM, as
+  // soon as it has fewer CUs), so splitting the chip between them only adds the ramps of more launches (cfg 2: 3.33 -> 3.7 -
+  // 5.1 ms per step); the digitiser on a 64-CU lane beside the next IF's K1 loses to the K2 that follows on all CUs.
+  return 0;
+}
+int overlap_mode(const frbch_handle* h) {
+  const uint32_t m = (h->cfg.overlap >> 24) & 3u;
+#ifdef FRBCH_EXPERIMENTS
+  static const int env = getenv("FRBCH_OVERLAP_MODE") ? atoi(getenv("FRBCH_OVERLAP_MODE")) : 0;
+  if (env > 0) return env;
+#endif
+  return m ? (int)m : 2;
+}
+bool overlap_usable(const frbch_handle* h) {
+  const Plan& pl = h->pl;
+  return !pl.coherent && pl.fast_k1_log2m && pl.fast_k1_wave && (pl.fast_k2_log2m || pl.fast_k2_m1) && pl.fast_k2_wave &&
+         overlap_front_cus(h) >= 8;
+}
+uint32_t overlap_batches(const frbch_handle* h, uint64_t nblocks) {
+  uint32_t v = (h->cfg.overlap >> 16) & 0xFFu;
+#ifdef FRBCH_EXPERIMENTS
+  static const int env = getenv("FRBCH_PIPE_BATCHES") ? atoi(getenv("FRBCH_PIPE_BATCHES")) : 0;
+  if (env > 0) v = (uint32_t)env;
+#endif
+  if (!v) v = (uint32_t)std::min<uint64_t>(4, nblocks / 24);    // batches of at least 24 blocks (ramp-up and tail of the persistent kernels)
+  return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(v, nblocks));
+}
+
 // Transform `nblocks` blocks starting `payload_off` bytes into the payload stream of d_frames.
 int engine_feed_run(frbch_handle* h, const uint8_t* d_frames, uint32_t frame_bytes, uint32_t header_bytes,
                     uint64_t payload_off, uint64_t nblocks, uint8_t* d_out, size_t cap, uint64_t* rows_written,
-                    dev_stream_t s, const uint32_t* d_fbad);
+                    dev_stream_t s, const uint32_t* d_fbad, Chain* chain);
 
 // `h_bad` (optional): one flag per frame of d_frames, 1 = the frame is flagged invalid or is a filler for a missing frame
 // number; `d_fbad` the same as a bitmap on the device.  Blocks that touch such a frame go through the generic K1, which
 // reads their samples as 0; all other blocks take the fast kernels as before.
+// `chain` (optional): the caller's chain of stages (a scan queues several IFs into one); else the call runs its own.
 int engine_feed(frbch_handle* h, const uint8_t* d_frames, uint32_t frame_bytes, uint32_t header_bytes,
                 uint64_t payload_off, uint64_t nblocks, uint8_t* d_out, size_t cap, uint64_t* rows_written,
-                dev_stream_t s, const uint8_t* h_bad = nullptr, uint64_t nfr_bad = 0, const uint32_t* d_fbad = nullptr) {
+                dev_stream_t s, const uint8_t* h_bad = nullptr, uint64_t nfr_bad = 0, const uint32_t* d_fbad = nullptr,
+                Chain* chain = nullptr) {
   const Plan& pl = h->pl;
   *rows_written = 0;
   bool any = false;
   for (uint64_t f = 0; h_bad && f < nfr_bad && !any; ++f) any = h_bad[f] != 0;
-  if (!any) return engine_feed_run(h, d_frames, frame_bytes, header_bytes, payload_off, nblocks, d_out, cap, rows_written, s, nullptr);
+  if (!any) return engine_feed_run(h, d_frames, frame_bytes, header_bytes, payload_off, nblocks, d_out, cap, rows_written, s, nullptr, chain);
   const uint64_t pb = frame_bytes - header_bytes;
   auto dirty = [&](uint64_t b) {
     const uint64_t a0 = payload_off + b * pl.block_stride_bytes, a1 = a0 + pl.block_payload_bytes - 1;
@@ -1078,23 +1365,66 @@ int engine_feed(frbch_handle* h, const uint8_t* d_frames, uint32_t frame_bytes, 
     uint64_t b1 = b0 + 1;
     while (b1 < nblocks && dirty(b1) == d0) ++b1;
     const int rc = engine_feed_run(h, d_frames, frame_bytes, header_bytes, payload_off + b0 * pl.block_stride_bytes, b1 - b0, d_out, cap,
-                                   rows_written, s, d0 ? d_fbad : nullptr);
+                                   rows_written, s, d0 ? d_fbad : nullptr, nullptr);
     if (rc) return rc;
     b0 = b1;
   }
   return FRBCH_OK;
 }
 
+// batches a run of `nblocks` blocks is cut into: equal sizes (no short tail launch), at most maxb blocks each, and -- when
+// the stages overlap -- at most half the spill (two regions in flight) and at least `want` batches
+static void plan_batches(const Plan& pl, uint64_t nblocks, bool overlap, uint32_t want, uint64_t* nbatch, uint64_t* per) {
+  const uint64_t cap = overlap ? std::max<uint64_t>(1, pl.maxb / 2) : pl.maxb;
+  uint64_t nb = (nblocks + cap - 1) / cap;
+  if (overlap) nb = std::max<uint64_t>(nb, want);
+  nb = std::max<uint64_t>(1, std::min<uint64_t>(nb, nblocks));
+  *nbatch = nb;
+  *per = nblocks ? (nblocks + nb - 1) / nb : 0;
+  if (*per) *nbatch = (nblocks + *per - 1) / *per;
+}
+uint64_t feed_stage_count(const frbch_handle* h, uint64_t nblocks, bool overlap) {
+  uint64_t nbatch = 0, per = 0;
+  plan_batches(h->pl, nblocks, overlap, overlap ? overlap_batches(h, nblocks) : 1, &nbatch, &per);
+  return nblocks ? nbatch : 0;
+}
+
 // one run of blocks; *rows_written is the running row count of the call (rows land behind those already written)
 int engine_feed_run(frbch_handle* h, const uint8_t* d_frames, uint32_t frame_bytes, uint32_t header_bytes,
                     uint64_t payload_off, uint64_t nblocks, uint8_t* d_out, size_t cap, uint64_t* rows_written,
-                    dev_stream_t s, const uint32_t* d_fbad) {
+                    dev_stream_t s, const uint32_t* d_fbad, Chain* outer) {
   const Plan& pl = h->pl;
-  const uint64_t nbatch = (nblocks + pl.maxb - 1) / pl.maxb;
-  const uint64_t per = nbatch ? (nblocks + nbatch - 1) / nbatch : 0;      // equal batches: no short tail launch
-  for (uint64_t b0 = 0; b0 < nblocks; b0 += per) {
+  if (!nblocks) return FRBCH_OK;
+  // own chain unless the caller brought one; blocks that touch flagged frames run in queue order on the caller's stream
+  Chain own;
+  Chain* ch = outer;
+  const bool may_overlap = !d_fbad && overlap_usable(h);
+  Lanes* ln = nullptr;
+  if (!ch && may_overlap) ln = get_lanes(h->device, overlap_front_cus(h));
+  if (!ch && overlap_mode(h) != 1) ln = nullptr;     // (mode 2 only overlaps across the IFs of a scan: the caller's chain)
+  const bool overlap = ch ? (ch->ln != nullptr && ch->mode == 1) : (ln != nullptr);   // batches cut for two regions in flight
+  uint64_t nbatch = 0, per = 0;
+  plan_batches(pl, nblocks, overlap, overlap ? overlap_batches(h, nblocks) : 1, &nbatch, &per);
+  if (!ch) {
+    chain_begin(&own, h, s, nbatch >= 2 ? ln : nullptr, (uint32_t)nbatch, pl.nif < 4, 1);
+    ch = &own;
+  }
+  const uint32_t nreg = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, pl.maxb / per));
+  if (!h->region_ev_made) {
+    for (auto& e : h->region_ev) (void)dev_event_create_sync(&e);
+    h->region_ev_made = true;
+  }
+  const uint64_t spill_blk = (uint64_t)(pl.c2 / pl.g) * pl.gs;      // cf per block of the spill
+  int rc = FRBCH_OK;
+  for (uint64_t b0 = 0; b0 < nblocks && !rc; b0 += per) {
     const uint32_t nb = (uint32_t)std::min<uint64_t>(per, nblocks - b0);
+    const uint32_t reg = (ch->ln && ch->mode == 1) ? (h->next_region++ % nreg) : 0;
+    const uint64_t rb0 = (uint64_t)reg * per;                        // first block of the region inside the work buffers
     KParams p = base_params(h);
+    p.spill += rb0 * spill_blk;
+    p.s_dc += rb0 * pl.c2;
+    p.p0 += rb0 * pl.c2;
+    h->stg_cur = h->stg ? h->stg + rb0 * pl.block_payload_bytes : nullptr;
     p.fbad = d_fbad;
     p.fbad_frame0 = 0;
     p.frames = d_frames;
@@ -1102,28 +1432,43 @@ int engine_feed_run(frbch_handle* h, const uint8_t* d_frames, uint32_t frame_byt
     p.header_bytes = header_bytes;
     p.payload_bytes = frame_bytes - header_bytes;
     p.payload_off = payload_off + b0 * pl.block_stride_bytes;
-    int rc = launch_front(h, p, nb, s);
-    if (rc) return rc;
+    // ---- front: K0, K1, Kc --------------------------------------------------------------------------------------
+    const dev_stream_t sf = chain_front_stream(ch);
+    const bool region_wait = h->region_busy[reg] && (ch->ln || outer);   // the back stage that read this region last must be through
+    if (region_wait) (void)dev_stream_wait(sf, h->region_ev[reg]);
+    h->region_busy[reg] = false;
+    const dev_stream_t sk = chain_k0_stream(ch, sf);
+    if (sk != sf && region_wait) (void)dev_stream_wait(sk, h->region_ev[reg]);
+    h->lane_cus = (ch->ln && sf == ch->ln->f) ? ch->ln->ncu_f : 0;
+    rc = launch_front(h, p, nb, sf, sk);
+    h->lane_cus = 0;
+    if (rc) break;
+    chain_front_done(ch, sf);
+    // ---- back: K2 (+ statistics and digitiser of a completed interval) ------------------------------------------
+    const dev_stream_t sb = chain_back_stream(ch);
+    if (h->quant_busy) {   // a digitiser of this handle on the back lane still reads the power buffer
+      (void)dev_stream_wait(sb, h->quant_ev);
+      h->quant_busy = false;
+    }
     const uint64_t rows = (uint64_t)nb * pl.rows_per_block;
     if (fused_ok(h)) {
-      if ((*rows_written + rows) * pl.row_bytes > cap)
-        return fail(h, FRBCH_E_CAPACITY, "output buffer too small");
+      if (out_extent(h, *rows_written + rows) > cap) { rc = fail(h, FRBCH_E_CAPACITY, "output buffer too small"); break; }
       p.out_mode = FRBCH_OUT_CODES;
       p.code_out = d_out;
       p.row0 = *rows_written;
-      rc = launch_back(h, p, nb, s);
-      if (rc) return rc;
+      rc = launch_back(h, p, nb, sb);
+      if (rc) break;
       *rows_written += rows;
       h->rows_out += rows;
     } else {
       rc = ensure_powbuf(h);
-      if (rc) return rc;
-      if (h->pow_rows + rows > h->pow_cap_rows) return fail(h, FRBCH_E_STATE, "power buffer overflow");
+      if (rc) break;
+      if (h->pow_rows + rows > h->pow_cap_rows) { rc = fail(h, FRBCH_E_STATE, "power buffer overflow"); break; }
       p.out_mode = FRBCH_OUT_FLOAT_POWER;
       p.power_out = h->powbuf;
       p.row0 = h->pow_rows;
       if (h->pow_rows == 0 && h->fused_chunks) {   // an interval starts here: K2 can sum it while writing it
-        CHECK_DEV(h, dev_memset(h->partial, 0, (size_t)h->fused_chunks * pl.ncol * 2 * sizeof(double), s), "clear partial sums");
+        if (dev_memset(h->partial, 0, (size_t)h->fused_chunks * pl.ncol * 2 * sizeof(double), sb) != 0) { rc = fail(h, FRBCH_E_DEVICE, "clear partial sums"); break; }
         h->fused_rows = 0;
         h->fused_valid = true;
       }
@@ -1131,8 +1476,8 @@ int engine_feed_run(frbch_handle* h, const uint8_t* d_frames, uint32_t frame_byt
         p.stat_partial = h->partial;
         p.stat_limit = pl.interval_rows;
       }
-      rc = launch_back(h, p, nb, s);
-      if (rc) return rc;
+      rc = launch_back(h, p, nb, sb);
+      if (rc) break;
       if (h->fused_valid) {
         if (p.stat_partial) {
           const uint64_t room = pl.interval_rows > h->pow_rows ? pl.interval_rows - h->pow_rows : 0;
@@ -1142,20 +1487,29 @@ int engine_feed_run(frbch_handle* h, const uint8_t* d_frames, uint32_t frame_byt
         }
       }
       h->pow_rows += rows;
-      while (!fused_ok(h) && h->pow_rows >= pl.interval_rows) {
-        rc = finalize_interval(h, pl.interval_rows, d_out, cap, rows_written, s);
-        if (rc) return rc;
-      }
+      while (!rc && !fused_ok(h) && h->pow_rows >= pl.interval_rows) rc = finalize_interval(h, pl.interval_rows, d_out, cap, rows_written, sb, ch);
+      if (rc) break;
+    }
+    chain_back_done(ch, sb);
+    if (ch->ln || outer) {
+      dev_event_record(h->region_ev[reg], sb);
+      h->region_busy[reg] = true;
     }
     h->blocks_done += nb;
   }
-  return FRBCH_OK;
+  h->stg_cur = nullptr;
+  if (ch == &own) chain_end(&own);
+  return rc;
 }
 
-int engine_flush(frbch_handle* h, uint8_t* d_out, size_t cap, uint64_t* rows_written, dev_stream_t s) {
+int engine_flush(frbch_handle* h, uint8_t* d_out, size_t cap, uint64_t* rows_written, dev_stream_t s, Chain* ch = nullptr) {
   *rows_written = 0;
   if (fused_ok(h) || h->pow_rows == 0) return FRBCH_OK;
-  return finalize_interval(h, std::min<uint64_t>(h->pow_rows, h->pl.interval_rows), d_out, cap, rows_written, s);
+  if (h->quant_busy) {
+    (void)dev_stream_wait(s, h->quant_ev);
+    h->quant_busy = false;
+  }
+  return finalize_interval(h, std::min<uint64_t>(h->pow_rows, h->pl.interval_rows), d_out, cap, rows_written, s, ch);
 }
 
 int set_identity_rescale(frbch_handle* h) {
@@ -1172,9 +1526,9 @@ int set_identity_rescale(frbch_handle* h) {
 // C ABI
 // =============================================================================================
 #ifdef FRBCH_EXPERIMENTS
-extern "C" const char* frbch_version(void) { return "frbch abi 2 backend " FRBCH_BACKEND_NAME " +experiments"; }
+extern "C" const char* frbch_version(void) { return "frbch abi 3 backend " FRBCH_BACKEND_NAME " +experiments"; }
 #else
-extern "C" const char* frbch_version(void) { return "frbch abi 2 backend " FRBCH_BACKEND_NAME; }
+extern "C" const char* frbch_version(void) { return "frbch abi 3 backend " FRBCH_BACKEND_NAME; }
 #endif
 
 extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
@@ -1405,6 +1759,68 @@ extern "C" int frbch_flush_device(frbch_handle* h, void* d_out, size_t out_cap_b
   return engine_flush(h, (uint8_t*)d_out, out_cap_bytes, rows_written, s);
 }
 
+extern "C" int frbch_scan_device(frbch_handle* const* ifs, uint32_t nif, const void* const* d_frames, size_t nframes,
+                                 uint32_t frame_bytes, uint32_t header_bytes, uint64_t payload_byte_offset, uint64_t nblocks,
+                                 int flush, void* d_rows, size_t row_pitch_bytes, uint64_t rows_cap, uint64_t* rows_written,
+                                 void* stream) {
+  if (!ifs || !nif || !ifs[0] || !rows_written || frame_bytes <= header_bytes) return FRBCH_E_ARG;
+  frbch_handle* h0 = ifs[0];
+  *rows_written = 0;
+  const Plan& pl = h0->pl;
+  for (uint32_t i = 0; i < nif; ++i) {
+    if (!ifs[i] || (nblocks && (!d_frames || !d_frames[i]))) return fail(h0, FRBCH_E_ARG, "null handle or frame pointer in the scan");
+    const Plan& a = ifs[i]->pl;
+    if (a.c != pl.c || a.nif != pl.nif || a.tscr != pl.tscr || a.row_bytes != pl.row_bytes || ifs[i]->cfg.nbit_out != h0->cfg.nbit_out ||
+        ifs[i]->device != h0->device || a.block_stride_bytes != pl.block_stride_bytes || a.block_payload_bytes != pl.block_payload_bytes)
+      return fail(h0, FRBCH_E_ARG, "the IFs of a scan must share device, nchan, freq_res, tscrunch, nbit and products");
+  }
+  if (row_pitch_bytes != (size_t)nif * pl.row_bytes) return fail(h0, FRBCH_E_ARG, "row_pitch_bytes must be nif * row_bytes of one IF");
+  if (!d_rows) return fail(h0, FRBCH_E_ARG, "null row buffer");
+  const uint64_t payload = (uint64_t)nframes * (frame_bytes - header_bytes);
+  if (nblocks && payload_byte_offset + (nblocks - 1) * pl.block_stride_bytes + pl.block_payload_bytes > payload)
+    return fail(h0, FRBCH_E_ARG, "frames do not cover the requested blocks");
+  DeviceGuard dg(h0->device);
+  dev_stream_t s = stream ? (dev_stream_t)stream : h0->stream;
+  for (uint32_t i = 0; i < nif; ++i) {
+    frbch_handle* h = ifs[i];
+    if (h->user_stream && h->user_stream != s) { const int rc = settle_user_stream(h); if (rc) return rc; }
+    if (stream) h->user_stream = s;
+    else if (h != h0) CHECK_DEV(h0, dev_sync(h->stream), "sync");   // (earlier work of this IF on its own stream)
+  }
+  // one chain over all IFs: the front stages of IF i + 1 overlap the back stages (and the flush) of IF i
+  Lanes* ln = overlap_usable(h0) ? get_lanes(h0->device, overlap_front_cus(h0)) : nullptr;
+  uint64_t stages = 0;
+  for (uint32_t i = 0; i < nif; ++i) stages += feed_stage_count(ifs[i], nblocks, ln != nullptr && overlap_mode(h0) == 1);
+  Chain ch;
+  chain_begin(&ch, h0, s, ln, (uint32_t)stages, pl.nif < 4, overlap_mode(h0));
+  const size_t seg = pl.row_bytes / pl.nif;                     // bytes of one product line of one IF
+  const uint64_t bits = pl.row_bytes * 8 / pl.ncol;
+  uint64_t rows_min = UINT64_MAX;
+  int rc = FRBCH_OK;
+  for (uint32_t i = 0; i < nif && !rc; ++i) {
+    frbch_handle* h = ifs[i];
+    h->out_pitch = (uint64_t)nif * pl.c;                        // values per (row, product) line of the scan's rows
+    uint8_t* dst = (uint8_t*)d_rows + (size_t)i * seg;
+    const size_t cap = (size_t)(rows_cap * row_pitch_bytes) - (size_t)i * seg;
+    uint64_t r1 = 0, r2 = 0;
+    if (nblocks) rc = engine_feed(h, (const uint8_t*)d_frames[i], frame_bytes, header_bytes, payload_byte_offset, nblocks, dst, cap, &r1, s,
+                                  nullptr, 0, nullptr, &ch);
+    if (!rc && flush) {
+      const dev_stream_t sb = (ch.ln && ch.backs) ? ch.s_back : s;
+      const uint64_t used = r1 * out_row_span(h);
+      rc = engine_flush(h, dst + used, cap - (size_t)used, &r2, sb, &ch);
+      if (!rc && r2) chain_back_touch(&ch);
+    }
+    h->out_pitch = 0;
+    if (rc && h != h0) fail(h0, rc, std::string("IF ") + std::to_string(i) + ": " + h->err);
+    rows_min = std::min(rows_min, r1 + r2);
+    (void)bits;
+  }
+  chain_end(&ch);
+  *rows_written = rows_min == UINT64_MAX ? 0 : rows_min;
+  return rc;
+}
+
 extern "C" int frbch_power_device(frbch_handle* h, const void* d_frames, size_t nframes, uint32_t frame_bytes,
                                   uint32_t header_bytes, uint64_t payload_byte_offset, uint64_t nblocks,
                                   float* d_power, size_t cap_bytes, void* stream) {
@@ -1429,7 +1845,7 @@ extern "C" int frbch_power_device(frbch_handle* h, const void* d_frames, size_t 
     p.header_bytes = header_bytes;
     p.payload_bytes = frame_bytes - header_bytes;
     p.payload_off = payload_byte_offset + b0 * pl.block_stride_bytes;
-    int rc = launch_front(h, p, nb, s);
+    int rc = launch_front(h, p, nb, s, s);
     if (rc) return rc;
     p.out_mode = FRBCH_OUT_FLOAT_POWER;
     p.power_out = d_power;

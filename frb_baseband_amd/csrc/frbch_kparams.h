@@ -59,6 +59,8 @@ struct KParams {
   float* power_out;         // [row][nif][C] float32, output channel order
   uint8_t* code_out;        // [row][nif][C] packed to nbit, output channel order
   uint64_t row0;            // first output row of block 0 of this launch inside *_out
+  uint64_t out_pitch;       // code_out only: values between the starts of consecutive (row, product) lines; = C for packed rows,
+                            // larger when the rows land in this IF's columns of a scan's row buffer (frbch_scan_device / frbch_run_scan)
   uint32_t div_magic, div_shift;  // x / payload_bytes = (t + ((x - t) >> 1)) >> div_shift, t = mulhi(magic, x)
   float lut[4];             // 2-bit level table
   float digi_mean, digi_scale, digi_max;
@@ -115,6 +117,8 @@ struct QuantParams {
   float digi_mean, digi_scale, digi_max;
   uint32_t grid_x;          // workgroups launched (grid-stride loop)
   int log2_c;
+  int log2_ncol;
+  uint64_t pitch;           // output values between consecutive (row, product) lines (KParams::out_pitch)
 };
 #define QUANT_GRID_X(p) ((p).grid_x)
 
@@ -130,6 +134,9 @@ struct ChirpParams {        // frbch_chirp_build: fills KParams::chirp once per 
 };
 
 // element (channel row, position) of one block of spill2 / of the chirp table; r = freq_res
+// value index of (row, product, first channel) in code_out: lines of out_pitch values per (row, product)
+#define FRBCH_CODE_INDEX(pitch, row, nif, prod, cout) ((((uint64_t)(row)) * (uint64_t)(nif) + (uint64_t)(prod)) * (uint64_t)(pitch) + (uint64_t)(cout))
+
 #define S2_INDEX(row, pos, r) (((((uint64_t)(row) >> 2) * (uint64_t)(r) + (uint64_t)(pos)) << 2) + (uint64_t)((row) & 3))
 
 #endif

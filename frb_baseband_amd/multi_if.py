@@ -151,6 +151,27 @@ def run_scan(channelisers, vdif_paths, out_fil: str) -> None:
         raise (ch.InputError if rc == -1 else ch.RunError)(channelisers[0]._err(rc))
 
 
+def scan_device(channelisers, d_frames_ptrs, nframes: int, frame_bytes: int, header_bytes: int, payload_off: int,
+                nblocks: int, d_rows_ptr: int, rows_cap: int, flush: bool = True, stream: int = 0) -> int:
+    """The same with everything resident in HBM: ``frbch_scan_device`` (include/frbch.h).  ``d_frames_ptrs[i]`` is the
+    device address of the frames of ``channelisers[i]`` (splice order); the rows of all IFs land in ONE row buffer
+    ``d_rows[row][product][IF-major channels]`` (row pitch = n x row_bytes of one IF).  Returns the rows written."""
+    import ctypes as C
+    from . import channeliser as ch
+    n = len(channelisers)
+    assert n == len(d_frames_ptrs) and n > 0
+    lib = channelisers[0].lib
+    handles = (C.c_void_p * n)(*[c._h for c in channelisers])
+    frames = (C.c_void_p * n)(*[int(x) for x in d_frames_ptrs])
+    rows = C.c_uint64(0)
+    pitch = n * channelisers[0].info.row_bytes
+    rc = lib.frbch_scan_device(handles, n, frames, nframes, frame_bytes, header_bytes, payload_off, nblocks,
+                               1 if flush else 0, d_rows_ptr, pitch, rows_cap, C.byref(rows), stream or None)
+    if rc < 0:
+        raise (ch.InputError if rc == -1 else ch.RunError)(channelisers[0]._err(rc))
+    return rows.value
+
+
 def process_scan(vdif_by_if: dict, *, freq_lsb_0: float, bw: float, nchan: int, nsec: float, start: float = 0.0,
                  pol: int = 2, nbit: int = 8, tscrunch: int = 1, keepBP: bool = False, source: str = "unknown",
                  ra: str = "00:00:00.0", dec: str = "00:00:00.0", telescope: str = "ONSALA85",

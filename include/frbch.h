@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define FRBCH_ABI_VERSION 2
+#define FRBCH_ABI_VERSION 3
 
 /* error codes (negative); 0 = ok.  process_vdif.py:193-198 turns a non-zero digifil exit status
  * into RunError; the CLI shim maps any of these to exit status 1 with frbch_strerror on stderr. */
@@ -78,7 +78,13 @@ typedef struct frbch_config {
   char datafile[512];          /* .hdr DATAFILE   (:129)                                      */
   uint32_t input_bits;         /* bits per sample of the VDIF: 2, or 1 (mode VDIF_8000-1024-16-1, spif2file.sh:58-61);
                                 * 0 = take it from the first frame header (host paths) / 2 (device paths)            */
-  uint32_t reserved1;
+  uint32_t overlap;            /* 0 in production (automatic).  Two lanes of the device work on streams with complementary CU
+                                * masks: bits 0..15 compute units of the front lane (K0, K1, Kc; multiple
+                                * of 8; 1 = no overlap: every kernel on the whole chip, one after the other); bits 24..25 what
+                                * runs on the back lane: 2 (automatic choice) = only the digitiser of a completed rescale
+                                * interval, beside the K1 of the next IF of a scan; 1 = K2, statistics and digitiser, beside the
+                                * K1 of the next batch (measured slower: both kernels scale with their share of the CUs), with
+                                * bits 16..23 = batches a call is cut into.  Every setting produces the same output.            */
   float levels[4];             /* 2-bit level table, state 0..3 -> voltage (process_vdif.py:157 passes the bare `-2`: DSPSR's
                                 * static table); all four 0 = the default -3.3359, -1, +1, +3.3359.  A run-time table in
                                 * every kernel, so another level scheme is a data change.                                  */
@@ -164,6 +170,19 @@ int frbch_run_file(frbch_handle* h, const char* vdif_path, const char* out_fil);
  * to the shortest IF as splice does.  out_fil may be a FIFO (same open flags as frbch_run_file).
  * Errors are reported through frbch_last_error(ifs[0]). */
 int frbch_run_scan(frbch_handle* const* ifs, uint32_t nif, const char* const* vdif_paths, const char* out_fil);
+
+/* The same scan with everything resident in HBM (the device-side form of frbch_run_scan): d_frames[i] holds
+ * the per-IF VDIF frames of ifs[i] (same frame geometry and length for all), `nblocks` filterbank blocks of every IF are
+ * transformed starting `payload_byte_offset` bytes into the payload streams, and the rows land in ONE row buffer
+ * d_rows[row][product][IF-major channels] -- ifs[0] (the highest IF, base2fil.sh:350,367) in the first nchan columns of every
+ * (row, product) line: the frequency concatenation `splice` does on the host (base2fil.sh:422) happens in the store
+ * addresses of the last kernel.  row_pitch_bytes = nif * (row_bytes of one IF); rows_cap rows fit in d_rows.  With `flush`
+ * the pending rescale interval of every IF is closed too (the end of the scan).  *rows_written = rows every IF delivered.
+ * The IFs go through the two lanes of DESIGN.md section 4b one behind the other: the front half of IF i + 1 overlaps the
+ * back half of IF i.  `stream` as in frbch_process_device.  Errors are reported through frbch_last_error(ifs[0]). */
+int frbch_scan_device(frbch_handle* const* ifs, uint32_t nif, const void* const* d_frames, size_t nframes,
+                      uint32_t frame_bytes, uint32_t header_bytes, uint64_t payload_byte_offset, uint64_t nblocks,
+                      int flush, void* d_rows, size_t row_pitch_bytes, uint64_t rows_cap, uint64_t* rows_written, void* stream);
 
 /* ---- streaming host path ----------------------------------------------------------------- */
 /* push whole or partial frames (byte stream starting at a frame boundary on the first call) */

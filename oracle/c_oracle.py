@@ -36,7 +36,7 @@ def block_power(payload: np.ndarray, nchan: int, freq_res: int, nblocks: int, po
     """payload bytes (headers stripped, whole blocks) -> float32 [nif][C][nblocks * R/tscr]."""
     lib = _load()
     n = 2 * nchan * freq_res
-    nif = 4 if pol_mode == 4 else 1
+    nif = 4 if pol_mode >= 4 else 1
     nt = freq_res // tscr
     plan = lib.frbo_plan_create(nchan, freq_res)
     out = np.empty((nif, nchan, nblocks * nt), dtype=np.float32)
@@ -52,14 +52,14 @@ def block_power(payload: np.ndarray, nchan: int, freq_res: int, nblocks: int, po
     return out
 
 
-def channelise_blocks(raw_frames: np.ndarray, bw: float, nchan: int, freq_res: int, nblocks: int):
-    """Frames -> power of the first nblocks (Stokes I); the timed body of bench.py's cpu_baseline."""
+def channelise_blocks(raw_frames: np.ndarray, bw: float, nchan: int, freq_res: int, nblocks: int, pol_mode: int = 2):
+    """Frames -> power of the first nblocks; the timed body of bench.py's cpu_baseline."""
     fb = 8032
     payload = raw_frames[: raw_frames.size // fb * fb].reshape(-1, fb)[:, 32:].reshape(-1)
-    return block_power(payload, nchan, freq_res, nblocks)
+    return block_power(payload, nchan, freq_res, nblocks, pol_mode)
 
 
-def _bench_worker(seconds: float, bw: float, nchan: int, seed: int = 0) -> float:
+def _bench_worker(seconds: float, bw: float, nchan: int, seed: int = 0, pol_mode: int = 2) -> float:
     """one `digifil_nthreads=1` process of the reference's per-IF fan-out (base2fil.sh:60-66,219): blocks/s"""
     import time
     from frb_baseband_amd import synth
@@ -70,11 +70,12 @@ def _bench_worker(seconds: float, bw: float, nchan: int, seed: int = 0) -> float
     t0 = time.perf_counter()
     nblk = 0
     while time.perf_counter() - t0 < seconds:
-        channelise_blocks(raw, bw, nchan, r, 2)
+        channelise_blocks(raw, bw, nchan, r, 2, pol_mode)
         nblk += 2
     return nblk * n / (time.perf_counter() - t0)
 
 
-if __name__ == "__main__":   # python -m oracle.c_oracle <seconds> <bw> <nchan> <seed>: prints samples/s (bench.py's all-cores leg)
+if __name__ == "__main__":   # python -m oracle.c_oracle <seconds> <bw> <nchan> <seed> [pol_mode]: prints samples/s (bench.py's all-cores leg)
     import sys
-    print(_bench_worker(float(sys.argv[1]), float(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])))
+    print(_bench_worker(float(sys.argv[1]), float(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]),
+                        int(sys.argv[5]) if len(sys.argv) > 5 else 2))

@@ -125,7 +125,7 @@ static void real_fft(frbo_plan* p, const float* x, cpx* spec) {
   }
 }
 
-/* one block: payload bytes (n/2) -> power[nif][c][r/tscr]; pol_mode 0,1,2,3,4 */
+/* one block: payload bytes (n/2) -> power[nif][c][r/tscr]; pol_mode 0,1,2,3,4,5 */
 void frbo_block_power(frbo_plan* p, const uint8_t* payload, int pol_mode, int tscr, float* power) {
   const size_t c = p->c, r = p->r, nt = r / (size_t)tscr;
   frbo_unpack_2bit(payload, p->n / 2, p->x0, p->x1);
@@ -154,11 +154,18 @@ void frbo_block_power(frbo_plan* p, const uint8_t* payload, int pol_mode, int ts
           s3 += p0.im * p1.re - p0.re * p1.im;      /* Im(p0 conj p1) */
         }
       }
+      if (pol_mode == 5) {                          /* Stokes I, Q, U, V of circular feeds (frb_oracle.py: iquv) */
+        power[(0 * c + k) * nt + t] = s0 + s1;
+        power[(1 * c + k) * nt + t] = 2.0f * s2;
+        power[(2 * c + k) * nt + t] = 2.0f * s3;
+        power[(3 * c + k) * nt + t] = s0 - s1;
+      } else {
       power[(0 * c + k) * nt + t] = s0;
       if (pol_mode == 4) {
         power[(1 * c + k) * nt + t] = s1;
         power[(2 * c + k) * nt + t] = s2;
         power[(3 * c + k) * nt + t] = s3;
+      }
       }
     }
   }

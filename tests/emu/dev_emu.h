@@ -83,6 +83,11 @@ static inline int dev_memset32(void* d, uint32_t v, size_t nwords, dev_stream_t)
 static inline int dev_sync(dev_stream_t) { return 0; }
 static inline int dev_stream_create(dev_stream_t* s) { *s = (void*)1; return 0; }
 static inline void dev_stream_destroy(dev_stream_t) {}
+// (the emulator runs everything in call order: lanes and events only exercise the engine's bookkeeping)
+static inline int dev_stream_create_masked(dev_stream_t* s, const uint32_t*, uint32_t) { *s = (void*)2; return 0; }
+static inline int dev_cu_count(int) { return 256; }
+static inline int dev_event_create_sync(int* e) { *e = 0; return 0; }
+static inline int dev_stream_wait(dev_stream_t, int) { return 0; }
 static inline int dev_check_launch() { return 0; }
 static inline int dev_host_alloc(void** p, size_t n) { *p = malloc(n); return *p ? 0 : -1; }
 static inline void dev_host_free(void* p) { free(p); }

@@ -7,7 +7,7 @@ from oracle import c_oracle
 from oracle import frb_oracle as o
 
 
-@pytest.mark.parametrize("c,r,pol,t", [(16, 64, 4, 2), (128, 512, 2, 1), (32, 64, 3, 4), (64, 512, 0, 8), (8, 16, 1, 1)])
+@pytest.mark.parametrize("c,r,pol,t", [(16, 64, 4, 2), (16, 64, 5, 1), (128, 512, 2, 1), (32, 64, 3, 4), (64, 512, 0, 8), (8, 16, 1, 1)])
 def test_c_port_matches_numpy_oracle(c, r, pol, t):
     n = 2 * c * r
     raw = synth.make_vdif(3 * n / 32e6 + 0.001, bw_mhz=16.0, nchan=c)

@@ -7,7 +7,9 @@ import sys
 import numpy as np
 import pytest
 
+from frb_baseband_amd import channeliser as ch
 from frb_baseband_amd import multi_if, sigproc, synth
+from tests import parity_util as pu
 from oracle import frb_oracle as o
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -125,3 +127,52 @@ def test_direct_scan_rejects_mixed_geometry(emu_lib, tmp_path):
         multi_if.run_scan([a, b], ["/nonexistent/a.vdif", "/nonexistent/b.vdif"], str(tmp_path / "o.fil"))
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(nchan=32, freq_res=64),                                   # interval = scan: everything digitised in the flush
+    dict(nchan=32, freq_res=64, pol=5, interval=0.004, maxb=3),    # four products, interval inside the scan, small batches
+    dict(nchan=32, freq_res=64, pol=4, nbit=2, tscr=2, interval=0.0),
+    dict(nchan=32, freq_res=64, nbit=16, interval=0.004, const=0, maxb=2),
+    dict(nchan=128, freq_res=512, overlap=160 | (3 << 16) | (1 << 24)),   # two lanes, K2 on the back lane, three batches per IF (emulator: queue order)
+    dict(nchan=128, freq_res=512, pol=5, overlap=192 | (2 << 24)),         # two lanes, the digitiser beside the next IF's K1
+])
+def test_scan_device_rows_are_the_splice_of_the_per_if_rows(emu_lib, kw):
+    """frbch_scan_device: every IF's rows land in its columns of one row buffer == the per-IF outputs side by side."""
+    kw = dict(kw)
+    overlap = kw.pop("overlap", 0)
+    nchan, bw, secs, nif_scan = kw.pop("nchan"), 16.0, 0.03, 3
+    raws = [synth.make_vdif(secs, bw_mhz=bw, nchan=nchan, if_index=i) for i in range(nif_scan)]
+    chans = []
+    for i in range(nif_scan):
+        cfg = pu.lib_cfg(emu_lib, -bw if i % 2 else bw, nchan, secs, **kw)
+        cfg.overlap = overlap
+        chans.append(ch.Channeliser(cfg, emu_lib))
+    info = chans[0].info
+    nfr = raws[0].size // 8032
+    nblocks = (nfr * 8000) // info.block_payload_bytes
+    rows = nblocks * info.rows_per_block
+    # per IF, packed rows
+    single = []
+    for c, raw in zip(chans, raws):
+        out = np.zeros(rows * info.row_bytes, np.uint8)
+        r1 = c.process_device(raw.ctypes.data, nfr, 8032, 32, 0, nblocks, out.ctypes.data, out.size)
+        r1 += c.flush_device(out.ctypes.data + r1 * info.row_bytes, out.size - r1 * info.row_bytes)
+        assert r1 == rows
+        single.append(out.reshape(rows, info.nif, -1))
+        c.reset()
+    want = np.concatenate(single, axis=2)
+    # the scan: one row buffer, in two calls (the second one flushes)
+    buf = np.zeros(rows * nif_scan * info.row_bytes, np.uint8)
+    half = nblocks // 2
+    ptrs = [r.ctypes.data for r in raws]
+    got1 = multi_if.scan_device(chans, ptrs, nfr, 8032, 32, 0, half, buf.ctypes.data, rows, flush=False)
+    off = got1 * nif_scan * info.row_bytes
+    got2 = multi_if.scan_device(chans, ptrs, nfr, 8032, 32, half * info.block_payload_bytes, nblocks - half,
+                                buf.ctypes.data + off, rows - got1, flush=True)
+    assert got1 + got2 == rows
+    np.testing.assert_array_equal(buf.reshape(want.shape), want)
+    with pytest.raises(ch.InputError):
+        multi_if.scan_device(chans, ptrs, nfr, 8032, 32, 0, nblocks + 1, buf.ctypes.data, rows)
+    for c in chans:
+        c.close()

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_ab.sh <other libfrbch.so> [bench args]: the same bench with the in-tree library and with another build, alternating (same box)
+# usage: tools/ab.sh <other libfrbch.so> [bench args]: the same bench with the in-tree library and with another build, alternating (same box)
 other=$1; shift
 run() {
   python3 -c "

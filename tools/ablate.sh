@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: [ARGS='--nchan 4096 --bw 64 --seconds 5'] tools_ablate.sh <tag> <flag values...>   (EXPERIMENTS build on the GPU box: bench per ablation mask)
+# usage: [ARGS='--nchan 4096 --bw 64 --seconds 5'] tools/ablate.sh <tag> <flag values...>   (EXPERIMENTS build on the GPU box: bench per ablation mask)
 tag=$1; shift
 for f in "$@"; do
   python3 bench.py --no-cpu --no-host --no-traffic --steps 10 --warmup 5 $ARGS --flags $f 2>/dev/null | python3 -c "

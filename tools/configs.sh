@@ -1,7 +1,7 @@
 #!/bin/bash
 # All BASELINE configurations in one go (run on the GPU box): short benches, one summary line each -> gpurun_out/sweep_<tag>.log
 tag=${1:-configs}
-bash tools_sweep.sh $tag \
+bash tools/sweep.sh $tag \
   "cfg1_128ch|--nchan 128 --bw 16" \
   "cfg2_1024ch|" \
   "cfg3_1024ch_d4|--pol 4" \

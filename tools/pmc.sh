@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh <tag> [bench args...]   -- PMC passes for the hot kernels (run on the GPU box)
+# usage: tools/pmc.sh <tag> [bench args...]   -- PMC passes for the hot kernels (run on the GPU box)
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/pmc_$tag

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_sweep.sh <tag> "<label>|<bench args>" ...   -- short bench runs (run on the GPU box), one summary line each
+# usage: tools/sweep.sh <tag> "<label>|<bench args>" ...   -- short bench runs (run on the GPU box), one summary line each
 tag=$1; shift
 out=gpurun_out/sweep_$tag; mkdir -p $out
 for spec in "$@"; do
