@@ -257,8 +257,19 @@ def collect_traffic(argv):
             cmd = ["rocprofv3", "--pmc", cnt, "--output-format", "csv", "-d", d, "--", sys.executable,
                    os.path.abspath(__file__)] + child + ["--pmc-child"]
             env = dict(os.environ, TMPDIR="/tmp")
-            pr = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150)
-            if pr.returncode != 0:
+            # own process group: on a timeout the profiler AND the python it started (which holds the GPU) are killed
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = pr.wait(timeout=240)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                pr.wait()
+                return None
+            if rc != 0:
                 return None
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if not files:
@@ -601,8 +612,10 @@ def main():
                 "launches_per_step": rec["launches"] / args.steps,
                 "algorithmic_bytes_per_launch": rec["algorithmic_bytes"] / max(1, rec["launches"]),
                 "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in timing.items() if v["launches"]},
-                "concurrency": "front stages (K0, K1, Kc) and back stages (K2, statistics, digitiser) run on two CU-masked streams "
-                               "and overlap: a kernel's launch duration is its time on ITS share of the CUs, the sum over kernels exceeds ms_per_step",
+                "concurrency": ("kernels run one after the other on the whole chip (frbch_config.overlap automatic = off: two CU-masked "
+                                "lanes were measured slower, profiles/r03_overlap_sweep_*.txt)") if (args.overlap & 0xFFFF) in (0, 1) else
+                               ("front stages (K0, K1, Kc) and back stages run on two CU-masked streams and overlap: a kernel's launch "
+                                "duration is its time on ITS share of the CUs, the sum over kernels exceeds ms_per_step"),
                 "valu": valu,
                 "whole_path": {"algorithmic_bytes_per_sample": round(bps, 3),
                                "achieved": round(value / world * 1e6 * bps / 1e9, 1),

@@ -45,7 +45,7 @@ class FrbchInfo(C.Structure):
         ("tsamp_s", C.c_double), ("tstart_mjd", C.c_double),
         ("fch1_mhz", C.c_double), ("foff_mhz", C.c_double),
         ("frame_bytes", C.c_uint32), ("header_bytes", C.c_uint32),
-        ("have_rescale", C.c_uint32), ("reserved", C.c_uint32),
+        ("have_rescale", C.c_uint32), ("diag", C.c_uint32),
         ("frames_seen", C.c_uint64), ("frames_invalid", C.c_uint64), ("frame_gaps", C.c_uint64),
         ("block_stride_bytes", C.c_uint64), ("nfilt_pos", C.c_uint32), ("nfilt_neg", C.c_uint32),
         ("frames_filled", C.c_uint64),

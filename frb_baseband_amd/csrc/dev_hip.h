@@ -105,6 +105,7 @@ static inline int dev_cu_count(int d) {
 // ordering-only events (no timestamps) and cross-stream waits
 static inline int dev_event_create_sync(hipEvent_t* e) { return hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess ? 0 : -1; }
 static inline int dev_stream_wait(dev_stream_t s, hipEvent_t e) { return hipStreamWaitEvent(s, e, 0) == hipSuccess ? 0 : -1; }
+static inline int dev_event_sync(hipEvent_t e) { return hipEventSynchronize(e) == hipSuccess ? 0 : -1; }
 static inline int dev_check_launch() { return hipGetLastError() == hipSuccess ? 0 : -1; }
 static inline int dev_host_alloc(void** p, size_t n) { return hipHostMalloc(p, n, hipHostMallocDefault) == hipSuccess ? 0 : -1; }
 static inline void dev_host_free(void* p) { if (p) (void)hipHostFree(p); }

@@ -57,7 +57,9 @@ struct frbch_handle {
   std::string err;
   int device = 0;
   dev_stream_t stream = 0;
-  dev_stream_t user_stream = 0;   // last caller stream the device entry points launched on (0 = none pending)
+  dev_stream_t user_stream = 0;   // last caller stream the device entry points launched on (0 = none pending); never dereferenced
+  dev_event_t user_ev{};          // ... and the handle's own event recorded on it behind that work
+  bool user_ev_made = false;
   size_t lds_limit = 65536;
 
   // constant tables
@@ -127,6 +129,7 @@ struct frbch_handle {
   std::vector<dev_event_t> evpool; // ordering events, used round-robin
   size_t evnext = 0;
   uint32_t next_region = 0;        // spill region of the next batch
+  uint32_t diag = 0;               // frbch_info::diag
   dev_event_t quant_ev{};          // behind a digitiser that ran on the back lane (mode 2)
   bool quant_ev_made = false, quant_busy = false;
   int quant_lane_cus = 0;          // CUs of the lane the digitiser was sent to
@@ -1525,6 +1528,27 @@ int set_identity_rescale(frbch_handle* h) {
 // =============================================================================================
 // C ABI
 // =============================================================================================
+// Work the device entry points queued on a caller's stream (statistics writing offset / scale, the digitiser reading
+// them, the power buffer) must be complete before the handle's own stream or the host touches that state.
+// The caller's stream may be gone by then (a temporary stream of the caller's framework): what is waited for is an event of
+// the handle's own, recorded on that stream behind the call's work (mark_user_stream).
+static int settle_user_stream(frbch_handle* h) {
+  if (h->user_stream) {
+    h->user_stream = 0;                     // (cleared first: a failing wait must not wedge every later call)
+    if (h->user_ev_made && dev_event_sync(h->user_ev) != 0)
+      return fail(h, FRBCH_E_DEVICE, std::string("sync (caller stream): ") + dev_last_error_string());
+  }
+  return FRBCH_OK;
+}
+static void mark_user_stream(frbch_handle* h, dev_stream_t s) {
+  if (!h->user_ev_made) {
+    if (dev_event_create_sync(&h->user_ev) != 0) return;
+    h->user_ev_made = true;
+  }
+  dev_event_record(h->user_ev, s);
+  h->user_stream = s;
+}
+
 #ifdef FRBCH_EXPERIMENTS
 extern "C" const char* frbch_version(void) { return "frbch abi 3 backend " FRBCH_BACKEND_NAME " +experiments"; }
 #else
@@ -1623,7 +1647,7 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
 extern "C" void frbch_close(frbch_handle* h) {
   if (!h) return;
   DeviceGuard dg(h->device);
-  if (h->user_stream) (void)dev_sync(h->user_stream);
+  (void)settle_user_stream(h);
   if (h->stream) (void)dev_sync(h->stream);
   drain_events(h);
   dev_free(h->tw_r); dev_free(h->tw_c2); dev_free(h->tw_nhi); dev_free(h->tw_nlo);
@@ -1635,6 +1659,10 @@ extern "C" void frbch_close(frbch_handle* h) {
   dev_free(h->d_frames); dev_free(h->d_out); dev_free(h->stg); dev_free(h->d_fbad);
   for (int i = 0; i < 8; ++i) { dev_host_free(h->pin_in[i]); dev_host_free(h->pin_out[i]); }
   if (h->stream) dev_stream_destroy(h->stream);
+  if (h->user_ev_made) dev_event_destroy(h->user_ev);
+  if (h->quant_ev_made) dev_event_destroy(h->quant_ev);
+  if (h->region_ev_made) for (auto& e : h->region_ev) dev_event_destroy(e);
+  for (auto& e : h->evpool) dev_event_destroy(e);
   delete h;
 }
 
@@ -1659,6 +1687,7 @@ extern "C" int frbch_get_info(frbch_handle* h, frbch_info* info) {
   info->frame_bytes = h->have_vdif ? h->v0.frame_bytes : 0;
   info->header_bytes = h->have_vdif ? h->v0.header_bytes() : 0;
   info->have_rescale = h->have_scale ? 1 : 0;
+  info->diag = h->diag;
   info->frames_seen = h->frames_seen;
   info->frames_invalid = h->frames_invalid;
   info->frame_gaps = h->frame_gaps;
@@ -1666,16 +1695,6 @@ extern "C" int frbch_get_info(frbch_handle* h, frbch_info* info) {
   info->block_stride_bytes = pl.block_stride_bytes;
   info->nfilt_pos = (uint32_t)pl.nfilt_pos;
   info->nfilt_neg = (uint32_t)pl.nfilt_neg;
-  return FRBCH_OK;
-}
-
-// Work the device entry points queued on a caller's stream (statistics writing offset / scale, the digitiser reading
-// them, the power buffer) must be complete before the handle's own stream or the host touches that state.
-static int settle_user_stream(frbch_handle* h) {
-  if (h->user_stream) {
-    CHECK_DEV(h, dev_sync(h->user_stream), "sync (caller stream)");
-    h->user_stream = 0;
-  }
   return FRBCH_OK;
 }
 
@@ -1741,10 +1760,11 @@ extern "C" int frbch_process_device(frbch_handle* h, const void* d_frames, size_
   dev_stream_t s = stream ? (dev_stream_t)stream : h->stream;
   if (stream) {
     if (h->user_stream && h->user_stream != s) { const int rc = settle_user_stream(h); if (rc) return rc; }
-    h->user_stream = s;
   }
-  return engine_feed(h, (const uint8_t*)d_frames, frame_bytes, header_bytes, payload_byte_offset, nblocks,
-                     (uint8_t*)d_out, out_cap_bytes, rows_written, s);
+  const int rc = engine_feed(h, (const uint8_t*)d_frames, frame_bytes, header_bytes, payload_byte_offset, nblocks,
+                             (uint8_t*)d_out, out_cap_bytes, rows_written, s);
+  if (stream) mark_user_stream(h, s);
+  return rc;
 }
 
 extern "C" int frbch_flush_device(frbch_handle* h, void* d_out, size_t out_cap_bytes, uint64_t* rows_written,
@@ -1754,9 +1774,10 @@ extern "C" int frbch_flush_device(frbch_handle* h, void* d_out, size_t out_cap_b
   dev_stream_t s = stream ? (dev_stream_t)stream : h->stream;
   if (stream) {
     if (h->user_stream && h->user_stream != s) { const int rc = settle_user_stream(h); if (rc) return rc; }
-    h->user_stream = s;
   }
-  return engine_flush(h, (uint8_t*)d_out, out_cap_bytes, rows_written, s);
+  const int rc = engine_flush(h, (uint8_t*)d_out, out_cap_bytes, rows_written, s);
+  if (stream) mark_user_stream(h, s);
+  return rc;
 }
 
 extern "C" int frbch_scan_device(frbch_handle* const* ifs, uint32_t nif, const void* const* d_frames, size_t nframes,
@@ -1784,8 +1805,7 @@ extern "C" int frbch_scan_device(frbch_handle* const* ifs, uint32_t nif, const v
   for (uint32_t i = 0; i < nif; ++i) {
     frbch_handle* h = ifs[i];
     if (h->user_stream && h->user_stream != s) { const int rc = settle_user_stream(h); if (rc) return rc; }
-    if (stream) h->user_stream = s;
-    else if (h != h0) CHECK_DEV(h0, dev_sync(h->stream), "sync");   // (earlier work of this IF on its own stream)
+    if (!stream && h != h0) CHECK_DEV(h0, dev_sync(h->stream), "sync");   // (earlier work of this IF on its own stream)
   }
   // one chain over all IFs: the front stages of IF i + 1 overlap the back stages (and the flush) of IF i
   Lanes* ln = overlap_usable(h0) ? get_lanes(h0->device, overlap_front_cus(h0)) : nullptr;
@@ -1817,6 +1837,8 @@ extern "C" int frbch_scan_device(frbch_handle* const* ifs, uint32_t nif, const v
     (void)bits;
   }
   chain_end(&ch);
+  if (stream)
+    for (uint32_t i = 0; i < nif; ++i) mark_user_stream(ifs[i], s);
   *rows_written = rows_min == UINT64_MAX ? 0 : rows_min;
   return rc;
 }
@@ -1835,7 +1857,6 @@ extern "C" int frbch_power_device(frbch_handle* h, const void* d_frames, size_t 
   dev_stream_t s = stream ? (dev_stream_t)stream : h->stream;
   if (stream) {
     if (h->user_stream && h->user_stream != s) { const int rc = settle_user_stream(h); if (rc) return rc; }
-    h->user_stream = s;
   }
   for (uint64_t b0 = 0; b0 < nblocks; b0 += pl.maxb) {
     const uint32_t nb = (uint32_t)std::min<uint64_t>(pl.maxb, nblocks - b0);
@@ -1853,6 +1874,7 @@ extern "C" int frbch_power_device(frbch_handle* h, const void* d_frames, size_t 
     rc = launch_back(h, p, nb, s);
     if (rc) return rc;
   }
+  if (stream) mark_user_stream(h, s);
   return FRBCH_OK;
 }
 
@@ -1874,7 +1896,6 @@ extern "C" int frbch_unpack_device(frbch_handle* h, const void* d_frames, size_t
   dev_stream_t s = stream ? (dev_stream_t)stream : h->stream;
   if (stream) {
     if (h->user_stream && h->user_stream != s) { const int rc = settle_user_stream(h); if (rc) return rc; }
-    h->user_stream = s;
   }
   KParams p = base_params(h);
   p.frames = (const uint8_t*)d_frames;
@@ -1894,6 +1915,7 @@ extern "C" int frbch_unpack_device(frbch_handle* h, const void* d_frames, size_t
 #endif
   }
   CHECK_DEV(h, dev_check_launch(), "launch unpack tap");
+  if (stream) mark_user_stream(h, s);
   return FRBCH_OK;
 }
 
@@ -1906,7 +1928,7 @@ extern "C" int frbch_set_profiling(frbch_handle* h, int enable) {
 extern "C" int frbch_timing_reset(frbch_handle* h) {
   if (!h) return FRBCH_E_ARG;
   DeviceGuard dg(h->device);
-  if (h->user_stream) (void)dev_sync(h->user_stream);
+  (void)settle_user_stream(h);
   (void)dev_sync(h->stream);
   drain_events(h);
   for (int i = 0; i < KID_COUNT; ++i) h->acc_ms[i] = h->acc_bytes[i] = 0.0, h->acc_launches[i] = 0;
@@ -1998,13 +2020,15 @@ int queue_rows(frbch_handle* h, uint64_t rows) {
 }
 
 // every frame header of the stream is checked once: geometry must match the first frame (else the
-// stream is corrupt or mis-framed: error); invalid flags and frame-number jumps are only counted,
-// the data is used as is because the reference always passes -cont (process_vdif.py:157,160)
+// stream is corrupt or mis-framed: error); frames flagged invalid are counted and marked (their samples enter the
+// filterbank as 0), a forward jump of the frame number is filled with zero-valued filler frames so that the stream stays
+// contiguous in time (-cont, process_vdif.py:157,160), a backward jump is only counted
 int check_headers(frbch_handle* h) {
   const uint64_t fb = h->v0.frame_bytes;
   const double fps_d = h->pl.rate_in * 2.0 * h->pl.in_bits / 8.0 / h->v0.payload_bytes();
   const uint64_t fps = (uint64_t)llround(fps_d);
-  while (h->checked_bytes + 16 <= h->carry.size()) {
+  // a frame is looked at once its whole header is there (a filler copies header_bytes() of it: 32 for non-legacy VDIF)
+  while (h->checked_bytes + h->v0.header_bytes() <= h->carry.size()) {
     VdifInfo v;
     parse_vdif_header(h->carry.data() + h->checked_bytes, &v);
     if (v.frame_bytes != h->v0.frame_bytes || v.legacy != h->v0.legacy || v.bits_per_sample != h->v0.bits_per_sample ||
@@ -2182,6 +2206,8 @@ struct PipeQueue {          // ring of pinned slots between the engine thread an
   uint64_t offs[kMaxSlots] = {0};   // output: file offset of the slot's bytes (regular files: positional writes)
   bool stop = false;
   int error = 0;
+  uint64_t seq_off = 0;          // output: every byte below this file offset has been written (writers that cannot use the
+  std::vector<std::pair<uint64_t, size_t>> done_off;   // mapping take turns in file order); pieces finished out of order
 };
 bool pwrite_all(int fd, const uint8_t* p, size_t n, uint64_t off) {
   while (n) {
@@ -2307,14 +2333,6 @@ int run_pipelined(frbch_handle* const* hs, uint32_t nif, const int* in_fds, int 
   uint8_t* omap = nullptr;                              // set by the preallocation thread
   std::atomic<int> pre_done{out_expect ? 0 : 1};
   std::thread prealloc;
-  if (out_expect)
-    prealloc = std::thread([&]() {
-      if (posix_fallocate(out_fd, 0, (off_t)out_expect) == 0) {
-        void* m = mmap(nullptr, (size_t)out_expect, PROT_READ | PROT_WRITE, MAP_SHARED, out_fd, 0);
-        if (m != MAP_FAILED) omap = (uint8_t*)m;
-      }
-      pre_done.store(1, std::memory_order_release);    // (without a mapping the writers fall back to positional writes)
-    });
   const int NWR = out_expect ? NSO : 1;                 // writer threads (each owns one slot when the output is mapped)
   if (h0->pin_in_cap < in_cap || h0->pin_out_cap < out_cap) {
     for (int i = 0; i < kMaxSlots; ++i) {
@@ -2330,6 +2348,21 @@ int run_pipelined(frbch_handle* const* hs, uint32_t nif, const int* in_fds, int 
     if ((!inbuf[i] && dev_host_alloc((void**)&inbuf[i], in_cap) != 0) || (!outbuf[i] && dev_host_alloc((void**)&outbuf[i], out_cap) != 0))
       return fail(h0, FRBCH_E_NOMEM, "pinned staging buffers");
   auto release = [&]() {};   // (the rings stay with the handle until frbch_close)
+  // (started only now: no early return is left between here and the join at the end of this function)
+  h0->diag &= ~1u;
+  if (out_expect)
+    prealloc = std::thread([&]() {
+#ifdef FRBCH_TEST_HOOKS
+      const bool refuse = getenv("FRBCH_TEST_NO_MMAP") != nullptr;   // (emulator build only: exercises the writers' fallback)
+#else
+      const bool refuse = false;
+#endif
+      if (!refuse && posix_fallocate(out_fd, 0, (off_t)out_expect) == 0) {
+        void* m = mmap(nullptr, (size_t)out_expect, PROT_READ | PROT_WRITE, MAP_SHARED, out_fd, 0);   // needs a descriptor opened O_RDWR (open_output)
+        if (m != MAP_FAILED) omap = (uint8_t*)m;
+      }
+      pre_done.store(1, std::memory_order_release);    // (without a mapping the writers take turns: one sequential stream of write() calls)
+    });
 
   PHASE_MARK(pc, "pinned rings");
   // every batch's frames travel in pieces of whole frames that fit a pinned buffer; batch rounds go IF by IF
@@ -2393,8 +2426,33 @@ int run_pipelined(frbch_handle* const* hs, uint32_t nif, const int* in_fds, int 
         bool ok = true;
         if (NWR > 1) {
           while (!pre_done.load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(50));
-          if (omap && off + n <= out_expect) memcpy(omap + off, outbuf[slot], n);
-          else ok = pwrite_all(out_fd, outbuf[slot], n, off);
+          if (omap && off + n <= out_expect) {
+            memcpy(omap + off, outbuf[slot], n);
+          } else {
+            // no mapping (or more bytes than expected): the writers take turns in file order -- ONE sequential stream of
+            // writes, never concurrent positional writes into one inode (measured slower than a single writer)
+            {
+              std::unique_lock<std::mutex> lk(qout.m);
+              qout.cv.wait(lk, [&] { return qout.seq_off == off || qout.error; });
+            }
+            ok = pwrite_all(out_fd, outbuf[slot], n, off);
+          }
+          {
+            std::lock_guard<std::mutex> lk(qout.m);
+            if (qout.seq_off == off) qout.seq_off = off + n;    // (mapped copies advance it too, so that a later unmapped slot finds its turn)
+            else qout.done_off.push_back({off, n});
+            for (bool moved = true; moved;) {
+              moved = false;
+              for (size_t k = 0; k < qout.done_off.size(); ++k)
+                if (qout.done_off[k].first == qout.seq_off) {
+                  qout.seq_off += qout.done_off[k].second;
+                  qout.done_off.erase(qout.done_off.begin() + (long)k);
+                  moved = true;
+                  break;
+                }
+            }
+            qout.cv.notify_all();
+          }
         } else {
           ok = write_all(out_fd, outbuf[slot], n);
         }
@@ -2566,12 +2624,29 @@ int run_pipelined(frbch_handle* const* hs, uint32_t nif, const int* in_fds, int 
     if (!rc && qout.error) rc = fail(h0, FRBCH_E_IO, std::string("write: ") + strerror(qout.error));
   }
   if (prealloc.joinable()) prealloc.join();
-  if (omap) munmap(omap, (size_t)out_expect);
+  if (omap) {
+    munmap(omap, (size_t)out_expect);
+    h0->diag |= 1u;            // frbch_info::diag bit 0: the output went through the shared mapping
+  }
   if (out_expect && out_off != out_expect && ftruncate(out_fd, (off_t)out_off) != 0 && !rc)
     rc = fail(h0, FRBCH_E_IO, std::string("ftruncate: ") + strerror(errno));
   PHASE_MARK(pc, "writers drained");
   release();
   return rc;
+}
+
+// The output of a whole-file call: INSTALL.md:32-35 -- no O_EXCL, so that a pre-made FIFO (base2fil.sh:348-349) can be the
+// target; never unlinked, never seeked.  A regular file (or a new one) is opened O_RDWR: the preallocated shared mapping of
+// run_pipelined needs read access to the descriptor (mmap of a write-only descriptor fails with EACCES); FIFOs, devices and
+// files that only grant write access keep O_WRONLY and ONE sequential writer.
+int open_output(const char* path) {
+  struct stat st;
+  const bool special = stat(path, &st) == 0 && !S_ISREG(st.st_mode);
+  if (!special) {
+    const int fd = open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
+    if (fd >= 0 || (errno != EACCES && errno != EPERM)) return fd;
+  }
+  return open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
 }
 
 int run_file_pipelined(frbch_handle* h, int in_fd, int out_fd) {
@@ -2589,8 +2664,7 @@ extern "C" int frbch_run_file(frbch_handle* h, const char* vdif_path, const char
     if (in_fd < 0) return fail(h, FRBCH_E_IO, std::string("cannot open ") + vdif_path + ": " + strerror(errno));
     struct stat st;
     if (fstat(in_fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= 32 && !h->have_vdif && vdif_file_contiguous(in_fd, h->cfg)) {
-      // INSTALL.md:32-35: no O_EXCL, so that a pre-made FIFO (base2fil.sh:348-349) can be the target
-      const int out_fd = open(out_fil, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+      const int out_fd = open_output(out_fil);
       if (out_fd < 0) {
         close(in_fd);
         return fail(h, FRBCH_E_IO, std::string("cannot open ") + out_fil + ": " + strerror(errno));
@@ -2693,7 +2767,7 @@ extern "C" int frbch_run_scan(frbch_handle* const* ifs, uint32_t nif, const char
     ifs[i]->sink_rows_cap = rows_cap;
   }
   if (!rc) {
-    fd = open(out_fil, O_WRONLY | O_CREAT | O_TRUNC, 0644);   // no O_EXCL: may be a FIFO (INSTALL.md:32-35)
+    fd = open_output(out_fil);   // no O_EXCL: may be a FIFO (INSTALL.md:32-35)
     if (fd < 0) rc = fail(h0, FRBCH_E_IO, std::string("cannot open ") + out_fil + ": " + strerror(errno));
   }
   if (!rc && !(h0->cfg.flags & kFlagNoPipeline)) {   // regular input files: overlapped read / transform / write (run_pipelined)

@@ -108,7 +108,8 @@ typedef struct frbch_info {
   double fch1_mhz, foff_mhz;
   uint32_t frame_bytes, header_bytes;
   uint32_t have_rescale;       /* offset/scale are defined                                     */
-  uint32_t reserved;
+  uint32_t diag;               /* diagnostics of the last call: bit 0 = the whole-file path wrote a regular output file through its
+                                  preallocated shared mapping (parallel copies) instead of write() calls                     */
   uint64_t frames_seen;        /* host streaming path: frames whose header was checked           */
   uint64_t frames_invalid;     /* ... with the VDIF invalid bit set: their samples enter the filterbank as 0 (the level table's
                                   mean), extract_baseband_chunk.py:56-69 reads the same bit                            */

@@ -88,6 +88,7 @@ static inline int dev_stream_create_masked(dev_stream_t* s, const uint32_t*, uin
 static inline int dev_cu_count(int) { return 256; }
 static inline int dev_event_create_sync(int* e) { *e = 0; return 0; }
 static inline int dev_stream_wait(dev_stream_t, int) { return 0; }
+static inline int dev_event_sync(int) { return 0; }
 static inline int dev_check_launch() { return 0; }
 static inline int dev_host_alloc(void** p, size_t n) { *p = malloc(n); return *p ? 0 : -1; }
 static inline void dev_host_free(void* p) { free(p); }

@@ -193,7 +193,7 @@ def test_post_command_line(emu_lib, tmp_path, monkeypatch):
     assert os.path.exists(str(tmp_path / "a_DM10.00.dat")) and os.path.exists(str(tmp_path / "a_DM11.00.inf"))
 
 
-def test_whole_file_path_with_a_mapped_output_equals_the_stream_path(emu_lib, tmp_path):
+def test_whole_file_path_with_a_mapped_output_equals_the_stream_path(emu_lib, tmp_path, monkeypatch):
     """outputs of 8 MB and more are preallocated and written through a shared mapping by one writer per slot: same
     bytes as push / pull, file length exact, also when rows are emitted interval by interval"""
     raw = synth.make_vdif(0.56, bw_mhz=16.0, nchan=32)
@@ -207,8 +207,17 @@ def test_whole_file_path_with_a_mapped_output_equals_the_stream_path(emu_lib, tm
         out = str(tmp_path / f"big_{const}.fil")
         with ch.Channeliser(cfg, emu_lib) as c:
             c.run_file(vd, out)
+            assert c.get_info().diag & 1, "the output did not go through the shared mapping (ADVICE r2: O_WRONLY descriptor)"
             c.reset()
             c.run_file(vd, out)                   # again into the existing file (O_TRUNC, then preallocated anew)
+            assert c.get_info().diag & 1
+        assert open(out, "rb").read() == want
+        # no mapping (refused here by the emulator build's test hook): the slot writers take turns in file order
+        monkeypatch.setenv("FRBCH_TEST_NO_MMAP", "1")
+        with ch.Channeliser(cfg, emu_lib) as c:
+            c.run_file(vd, out)
+            assert not (c.get_info().diag & 1)
+        monkeypatch.delenv("FRBCH_TEST_NO_MMAP")
         assert open(out, "rb").read() == want
 
 
