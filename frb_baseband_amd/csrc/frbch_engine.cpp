@@ -1716,8 +1716,8 @@ extern "C" int frbch_reset(frbch_handle* h) {
   h->outq.clear();
   h->outq_pos = 0;
   h->skip_bytes = 0;
-  dev_free(h->d_frames); h->d_frames = nullptr;
-  dev_free(h->d_out); h->d_out = nullptr;
+  // (the staging areas stay: hipMalloc of the gigabytes a four-product interval needs costs ~0.25 s per handle, which a
+  // scan of 8 IFs paid in every call -- 1.9 of 2.2 s, profiles/r03_scan_host_path.txt; stream_begin re-uses them)
   const bool off = h->pl.interval_rows == 0;
   h->have_scale = off;
   h->scale_frozen = off;
@@ -1988,21 +1988,47 @@ int stream_begin(frbch_handle* h, const uint8_t* first_frame) {
   // device staging: frames of one launch batch, output of one batch (+ a completed interval)
   const uint64_t pb = v.payload_bytes();
   const uint64_t nfr = ((uint64_t)(pl.maxb - 1) * pl.block_stride_bytes + pl.block_payload_bytes + pb - 1) / pb + 2;
-  h->d_frames_cap = nfr * v.frame_bytes;
-  CHECK_DEV(h, dev_malloc((void**)&h->d_frames, h->d_frames_cap), "hipMalloc(frame staging)");
-  const uint64_t burst_rows = pl.interval_rows + 2ull * pl.maxb * pl.rows_per_block;
-  h->d_out_cap = burst_rows * pl.row_bytes;
-  CHECK_DEV(h, dev_malloc((void**)&h->d_out, h->d_out_cap), "hipMalloc(output staging)");
+  const size_t want_frames = (size_t)(nfr * v.frame_bytes);
+  if (!h->d_frames || h->d_frames_cap < want_frames) {
+    dev_free(h->d_frames);
+    h->d_frames = nullptr;
+    h->d_frames_cap = want_frames;
+    CHECK_DEV(h, dev_malloc((void**)&h->d_frames, h->d_frames_cap), "hipMalloc(frame staging)");
+  }
+  // scan mode: the rows go straight into the scan's row buffer (out_target); the staging area only carries the backlog of
+  // an IF that is ahead of the others (a few batches), never a whole interval
+  const uint64_t burst_rows = (h->sink ? 0 : pl.interval_rows) + 2ull * pl.maxb * pl.rows_per_block;
+  const size_t want_out = (size_t)(burst_rows * pl.row_bytes);
+  if (!h->d_out || h->d_out_cap < want_out) {
+    dev_free(h->d_out);
+    h->d_out = nullptr;
+    h->d_out_cap = want_out;
+    CHECK_DEV(h, dev_malloc((void**)&h->d_out, h->d_out_cap), "hipMalloc(output staging)");
+  }
   return FRBCH_OK;
+}
+
+// Where the rows of the next engine call of the host paths go: the handle's own staging area (packed rows), or -- scan mode --
+// straight into this IF's columns of the scan's row buffer, behind the rows it already holds: the frequency concatenation
+// happens in the store addresses of K2 / the digitiser (KParams::out_pitch), no copy.
+struct OutTarget { uint8_t* ptr; size_t cap; };
+OutTarget out_target(frbch_handle* h) {
+  if (!h->sink) {
+    h->out_pitch = 0;
+    return OutTarget{h->d_out, h->d_out_cap};
+  }
+  const Plan& pl = h->pl;
+  const uint64_t bits = pl.row_bytes * 8 / pl.ncol;
+  h->out_pitch = (uint64_t)h->sink_line_pitch * 8 / bits;        // values per (row, product) line of the scan's rows
+  const size_t row_pitch = h->sink_line_pitch * pl.nif;
+  const uint64_t room = h->sink_rows_cap > h->sink_rows ? h->sink_rows_cap - h->sink_rows : 0;
+  return OutTarget{h->sink + h->sink_rows * row_pitch, room ? (size_t)((room - 1) * row_pitch + (size_t)(pl.nif - 1) * h->sink_line_pitch + pl.row_bytes / pl.nif) : 0};
 }
 
 int queue_rows(frbch_handle* h, uint64_t rows) {
   if (!rows) return FRBCH_OK;
-  if (h->sink) {   // scan mode: frequency concatenation on the device, one 2-D copy per batch
+  if (h->sink) {   // scan mode: the rows are already in this IF's columns of the scan buffer (out_target)
     if (h->sink_rows + rows > h->sink_rows_cap) return fail(h, FRBCH_E_CAPACITY, "scan row buffer too small");
-    const size_t seg = h->pl.row_bytes / h->pl.nif;            // bytes of one product line of this IF
-    CHECK_DEV(h, dev_copy2d(h->sink + h->sink_rows * h->pl.nif * h->sink_line_pitch, h->sink_line_pitch, h->d_out, seg, seg,
-                            rows * h->pl.nif, h->stream), "copy rows into the scan buffer");
     CHECK_DEV(h, dev_sync(h->stream), "sync");
     h->sink_rows += rows;
     return FRBCH_OK;
@@ -2111,7 +2137,8 @@ int process_carry(frbch_handle* h) {
     const uint32_t* d_bad = nullptr;
     int rc = bad ? upload_bad_frames(h, bad, need_frames, &d_bad) : FRBCH_OK;
     if (rc) return rc;
-    rc = engine_feed(h, h->d_frames, (uint32_t)fb, (uint32_t)hb, h->skip_bytes, nb, h->d_out, h->d_out_cap,
+    const OutTarget ot = out_target(h);
+    rc = engine_feed(h, h->d_frames, (uint32_t)fb, (uint32_t)hb, h->skip_bytes, nb, ot.ptr, ot.cap,
                      &rows, h->stream, d_bad ? bad : nullptr, need_frames, d_bad);
     if (rc) return rc;
     rc = queue_rows(h, rows);  // also synchronises, so `src` may be released
@@ -2153,7 +2180,8 @@ extern "C" int frbch_flush(frbch_handle* h) {
   if (!h->have_vdif) return FRBCH_OK;
   DeviceGuard dg(h->device);
   uint64_t rows = 0;
-  int rc = engine_flush(h, h->d_out, h->d_out_cap, &rows, h->stream);
+  const OutTarget ot = out_target(h);
+  int rc = engine_flush(h, ot.ptr, ot.cap, &rows, h->stream);
   if (rc) return rc;
   return queue_rows(h, rows);
 }
@@ -2588,7 +2616,8 @@ int run_pipelined(frbch_handle* const* hs, uint32_t nif, const int* in_fds, int 
       const uint8_t* bad = bad_all[pc.ifx].data() + b.f0;
       const uint32_t* d_bad = nullptr;
       rc = upload_bad_frames(h, bad, b.nfr, &d_bad);
-      if (!rc) rc = engine_feed(h, h->d_frames, (uint32_t)fb, (uint32_t)hb, b.pay_off, b.nb, h->d_out, h->d_out_cap, &rows, h->stream,
+      const OutTarget ot = out_target(h);
+      if (!rc) rc = engine_feed(h, h->d_frames, (uint32_t)fb, (uint32_t)hb, b.pay_off, b.nb, ot.ptr, ot.cap, &rows, h->stream,
                                 d_bad ? bad : nullptr, b.nfr, d_bad);
       if (rc && h != h0) fail(h0, rc, std::string("IF ") + std::to_string(pc.ifx) + ": " + h->err);
       if (!rc && rows) rc = scan ? queue_rows(h, rows) : emit_bytes(h->d_out, (size_t)(rows * pl.row_bytes), h->stream);
@@ -2601,7 +2630,8 @@ int run_pipelined(frbch_handle* const* hs, uint32_t nif, const int* in_fds, int 
   for (uint32_t i = 0; i < nif && !rc; ++i) {
     frbch_handle* h = hs[i];
     uint64_t rows = 0;
-    rc = engine_flush(h, h->d_out, h->d_out_cap, &rows, h->stream);
+    const OutTarget ot = out_target(h);
+    rc = engine_flush(h, ot.ptr, ot.cap, &rows, h->stream);
     if (rc && h != h0) fail(h0, rc, std::string("IF ") + std::to_string(i) + ": " + h->err);
     if (!rc && rows) rc = scan ? queue_rows(h, rows) : emit_bytes(h->d_out, (size_t)(rows * h->pl.row_bytes), h->stream);
   }
@@ -2646,7 +2676,11 @@ int open_output(const char* path) {
     const int fd = open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
     if (fd >= 0 || (errno != EACCES && errno != EPERM)) return fd;
   }
-  return open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+#ifdef F_SETPIPE_SZ
+  if (fd >= 0 && special && S_ISFIFO(st.st_mode)) (void)fcntl(fd, F_SETPIPE_SZ, 1 << 20);   // a FIFO: 1 MiB instead of 64 KiB in flight (best effort)
+#endif
+  return fd;
 }
 
 int run_file_pipelined(frbch_handle* h, int in_fd, int out_fd) {
@@ -2756,7 +2790,7 @@ extern "C" int frbch_run_scan(frbch_handle* const* ifs, uint32_t nif, const char
     if (fd >= 0) close(fd);
     dev_host_free(stage);
     dev_free(d_rows);
-    for (uint32_t i = 0; i < nif; ++i) ifs[i]->sink = nullptr;
+    for (uint32_t i = 0; i < nif; ++i) { ifs[i]->sink = nullptr; ifs[i]->out_pitch = 0; }
   };
   for (uint32_t i = 0; i < nif && !rc; ++i) {
     in[i] = fopen(vdif_paths[i], "rb");

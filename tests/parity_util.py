@@ -14,7 +14,24 @@ from oracle import frb_oracle as o
 #    TIE_EPS_SIGMA (in units of the rescaled sigma, i.e. TIE_EPS_SIGMA * digi_scale code units:
 #    2e-3 of an 8-bit code, 0.5 of a 16-bit code) of a rounding boundary; such samples may differ
 #    by 1 and must stay below MISMATCH_FRAC_PER_SIGMA * digi_scale of all samples (2e-4 for 8 bit).
-POWER_RTOL = 1.1e-5
+POWER_RTOL = 1.1e-5     # the loosest bound any configuration needs (kept for callers that do not know N)
+
+# Per-configuration bound: an fp32 FFT chain of N = 2 C R points against the fp64 oracle errs like
+# eps * sqrt(log2 N), and a sum over T scrunched samples averages the (independent) errors down by sqrt(T).  Measured
+# maxima of |P - P_oracle| / channel mean on MI355X (profiles/r02_power_error_distribution.jsonl):
+_MEASURED_POWER_ERR = {(17, 1): 3.02e-6, (22, 1): 3.87e-6, (24, 1): 5.02e-6, (26, 8): 1.33e-6}
+
+
+def power_rtol(nchan, freq_res, tscr=1):
+    """2 x the measured maximum of that configuration; elsewhere 2 x the model 1.02e-6 sqrt(log2 N) / sqrt(min(T, 8))
+    (which reproduces the four measured points to within +-25 %)"""
+    import math
+    log2n = int(round(math.log2(2 * nchan * freq_res)))
+    t = min(int(tscr), 8)
+    meas = _MEASURED_POWER_ERR.get((log2n, t))
+    if meas is None:
+        meas = 1.02e-6 * math.sqrt(log2n) / math.sqrt(t)
+    return min(POWER_RTOL, 2.0 * meas)
 TIE_EPS_SIGMA = 1.0e-4
 MISMATCH_FRAC_PER_SIGMA = 1.0e-5
 CODE_TIE_EPS = TIE_EPS_SIGMA * 127.5 / 6.0          # 8-bit values, kept for reference
@@ -54,6 +71,22 @@ def expected_boundary_distance(ocfg):
     return np.abs(t - np.round(t))
 
 
+def check_code_arrays(ref_data, got_data, ocfg):
+    """digitised rows [t][product][chan] of ONE IF against the oracle's (`ocfg` = the oracle run that produced ref_data):
+    identical except at rounding ties, as check_codes; returns the number of differing codes"""
+    assert ocfg.nbit != -32 and ref_data.shape == got_data.shape
+    d = got_data.astype(np.int64) - ref_data.astype(np.int64)
+    bad = np.nonzero(d)
+    nbad = bad[0].size
+    if nbad:
+        assert np.abs(d).max() <= 1, "code differs by more than 1"
+        _mean, dscale, _vmax = o.digi_params(ocfg.nbit)
+        dist = expected_boundary_distance(ocfg)[: ref_data.shape[0]][bad]
+        assert dist.max() <= TIE_EPS_SIGMA * dscale, f"mismatch away from a rounding tie: {dist.max()}"
+        assert nbad <= max(2, MISMATCH_FRAC_PER_SIGMA * dscale * d.size), f"{nbad} of {d.size} codes differ"
+    return nbad
+
+
 def check_codes(ref_bytes, got_bytes, ocfg):
     fr = sigproc.read_fil(ref_bytes)
     fg = sigproc.read_fil(got_bytes)
@@ -70,23 +103,15 @@ def check_codes(ref_bytes, got_bytes, ocfg):
         sp = p.std(axis=2)
         slope = np.where(sp > 0, x.std(axis=2) / np.where(sp > 0, sp, 1.0), 1.0)   # [nif][C]
         slack = 1.0 if (ocfg.rescale_constant or ocfg.rescale_interval_s <= 0) else 1.5
-        tol = slack * POWER_RTOL * chan_mean * slope                        # [nif][C]
+        rtol = power_rtol(ocfg.nchan, ocfg.result["geometry"][0], ocfg.tscrunch)
+        tol = slack * rtol * chan_mean * slope                              # [nif][C]
         if ocfg.bw_mhz > 0:
             tol = tol[:, ::-1]
         err = np.abs(fg.data.astype(np.float64) - ref)
         bound = tol[None, :, :] + 2.5e-7 * np.abs(ref)
         assert np.all(err <= bound), f"float output off by {(err / bound).max():.2f} x the stated bound"
         return 0
-    d = fg.data.astype(np.int64) - fr.data.astype(np.int64)
-    bad = np.nonzero(d)
-    nbad = bad[0].size
-    if nbad:
-        assert np.abs(d).max() <= 1, "code differs by more than 1"
-        _mean, dscale, _vmax = o.digi_params(ocfg.nbit)
-        dist = expected_boundary_distance(ocfg)[bad]
-        assert dist.max() <= TIE_EPS_SIGMA * dscale, f"mismatch away from a rounding tie: {dist.max()}"
-        assert nbad <= max(2, MISMATCH_FRAC_PER_SIGMA * dscale * d.size), f"{nbad} of {d.size} codes differ"
-    return nbad
+    return check_code_arrays(fr.data, fg.data, ocfg)
 
 
 def run_streaming_case(lib, bw, nchan, secs, **kw):

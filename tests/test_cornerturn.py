@@ -80,7 +80,7 @@ def test_split_streams_feed_the_channeliser_in_place(emu_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["VDIF_8000-1024-16-2", "VDIF_8000-4096-32-2", "MARK5B-2048-16-2", "VDIF_8000-1024-16-1"])
+@pytest.mark.parametrize("mode", sorted(ct.MODES))
 def test_modes_match_the_oracle_on_the_gpu(hip_lib, mode):
     fps, recipe, bits = ct.MODES[mode]
     frames, hb, pin = recorder_frames(mode, 64, seed=5)

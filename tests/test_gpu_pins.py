@@ -200,7 +200,9 @@ def test_power_error_distribution(hip_lib, name, bw, nchan, secs, pol, tscr, kw)
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/power_error_distribution.jsonl", "a") as f:
         f.write(json.dumps(stats) + "\n")
-    assert rel <= pu.POWER_RTOL, stats
+    bound = pu.power_rtol(nchan, ocfg.result["geometry"][0], tscr)       # 2 x this configuration's own measured maximum
+    stats["bound"] = bound
+    assert rel <= bound, stats
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -230,15 +232,7 @@ def _scan_vs_oracle(tmp_path, nif, bw, nchan, secs, pol, tscr):
         want = sigproc.read_fil(ref).data
         mine = got.data[:, :, col * nchan:(col + 1) * nchan]
         assert mine.shape == want.shape, (mine.shape, want.shape)
-        diff = mine.astype(np.int64) - want.astype(np.int64)
-        nbad = np.count_nonzero(diff)
-        if nbad:                                                        # only at rounding ties of the oracle value
-            assert np.abs(diff).max() <= 1
-            dist = pu.expected_boundary_distance(cfg)[np.nonzero(diff)]
-            _m, dscale, _v = o.digi_params(8)
-            assert dist.max() <= pu.TIE_EPS_SIGMA * dscale
-            assert nbad <= max(2, pu.MISMATCH_FRAC_PER_SIGMA * dscale * diff.size)
-        total_bad += nbad
+        total_bad += pu.check_code_arrays(want, mine, cfg)              # identical except at rounding ties of the oracle value
         if col == 0:
             assert got.header["fch1"] == pytest.approx(sigproc.read_fil(ref).header["fch1"])
     return total_bad
@@ -251,8 +245,8 @@ def test_config3_as_stated_8_ifs_d4_t1_8bit(tmp_path):
 
 
 def test_config3_iquv_8_ifs(tmp_path):
-    """the IQUV spelling of the same configuration (north_star "full-Stokes IQUV"), 4 IFs"""
-    _scan_vs_oracle(tmp_path, 4, 32.0, 1024, 0.14, 5, 1)
+    """the IQUV spelling of the same configuration (north_star "full-Stokes IQUV"): 8 IFs, as stated"""
+    _scan_vs_oracle(tmp_path, 8, 32.0, 1024, 0.14, 5, 1)
 
 
 def test_config4_share_two_4096ch_ifs_one_gpu(tmp_path):
@@ -372,3 +366,89 @@ def test_invalid_frame_at_4096_channels(hip_lib):
         got = c.channelise_bytes(inv)
         assert c.get_info().frames_invalid == 1
     pu.check_codes(ref, got, ocfg)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Input variants through the FAST kernels: legacy 16-byte headers and 1000-byte payloads
+# (mode VDIF_1000-1024-16-2, spif2file.sh:48-52; header size logic base2fil.sh:137-147)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("payload,legacy", [(1000, 1), (8000, 1), (1000, 0)])
+def test_legacy_headers_and_small_payloads_through_the_fast_kernels(hip_lib, payload, legacy):
+    bw, nchan, secs = 32.0, 1024, 0.14
+    raw = synth.make_vdif(secs, bw_mhz=bw, nchan=nchan, payload_bytes=payload, legacy=legacy)
+    ocfg = pu.oracle_cfg(bw, nchan, secs)
+    ref = o.channelise(raw, ocfg)
+    hb = 16 if legacy else 32
+    fb = payload + hb
+    # host stream path (frbch_push: geometry from the first frame header) ...
+    with ch.Channeliser(pu.lib_cfg(hip_lib, bw, nchan, secs), hip_lib) as c:
+        c.set_profiling(True)
+        got = c.channelise_bytes(raw)
+        names = {k for k, v in c.get_timing().items() if v["launches"]}
+        info = c.get_info()
+    pu.check_codes(ref, got, ocfg)
+    assert info.frame_bytes == fb and info.header_bytes == hb
+    assert any(n.startswith("frbch_k1_wave") for n in names) and "frbch_k0_stage" in names, names   # not the generic K1
+    assert any(n.startswith("frbch_k2_wave") for n in names), names
+    # ... and the device-resident entry point with the frame geometry handed over
+    d_raw = DeviceBuffer.from_numpy(raw)
+    with ch.Channeliser(pu.lib_cfg(hip_lib, bw, nchan, secs), hip_lib) as c:
+        info = c.info
+        nfr = raw.size // fb
+        nblocks = (nfr * payload) // info.block_payload_bytes
+        rows = nblocks * info.rows_per_block
+        out = DeviceBuffer(rows * info.row_bytes)
+        r1 = c.process_device(d_raw.ptr.value, nfr, fb, hb, 0, nblocks, out.ptr.value, out.nbytes)
+        r2 = c.flush_device(out.ptr.value + r1 * info.row_bytes, out.nbytes - r1 * info.row_bytes)
+        assert r1 + r2 == rows
+        codes = out.to_numpy(np.uint8).reshape(rows, 1, nchan)
+    pu.check_code_arrays(sigproc.read_fil(ref).data[:rows], codes, ocfg)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# frbch_scan_device: the scan with everything in HBM (the bench's step), rows of all IFs in one row buffer
+# ------------------------------------------------------------------------------------------------------------------
+def _scan_device(hip_lib, nif, bw, nchan, secs, overlap=0, **kw):
+    raws = [synth.make_vdif(secs, bw_mhz=bw, nchan=nchan, if_index=i + 1) for i in range(nif)]
+    bufs = [DeviceBuffer.from_numpy(r) for r in raws]
+    chans, ocfgs = [], []
+    for i in range(nif):
+        sbw = bw if i % 2 else -bw
+        cfg = pu.lib_cfg(hip_lib, sbw, nchan, secs, **kw)
+        cfg.overlap = overlap
+        chans.append(ch.Channeliser(cfg, hip_lib))
+        ocfgs.append(pu.oracle_cfg(sbw, nchan, secs, **{k: v for k, v in kw.items() if k not in ("maxb", "flags")}))
+    info = chans[0].info
+    nfr = raws[0].size // 8032
+    nblocks = (nfr * 8000) // info.block_payload_bytes
+    rows = nblocks * info.rows_per_block
+    out = DeviceBuffer(rows * nif * info.row_bytes)
+    got = multi_if.scan_device(chans, [b.ptr.value for b in bufs], nfr, 8032, 32, 0, nblocks, out.ptr.value, rows)
+    assert got == rows
+    data = out.to_numpy(np.uint8 if kw.get("nbit", 8) == 8 else np.uint16).reshape(rows, info.nif, nif * nchan)
+    for c in chans:
+        c.close()
+    return raws, ocfgs, data, rows
+
+
+def test_scan_device_config3_as_stated_against_the_oracle(hip_lib):
+    """BASELINE configs[2] as the bench runs it: 8 IFs x 32 MHz -> 1024-ch IQUV, 8 bit, one call, one row buffer; every
+    IF's columns (all four products) against the oracle.  2 blocks per IF."""
+    raws, ocfgs, data, rows = _scan_device(hip_lib, 8, 32.0, 1024, 0.14, pol=5)
+    for i, (raw, ocfg) in enumerate(zip(raws, ocfgs)):
+        want = sigproc.read_fil(o.channelise(raw, ocfg)).data[:rows]
+        pu.check_code_arrays(want, data[:, :, i * 1024:(i + 1) * 1024], ocfg)
+
+
+@pytest.mark.parametrize("overlap,kw", [
+    (160 | (2 << 16) | (1 << 24), dict(pol=2, maxb=2)),                        # K2 on the back lane, two batches per IF
+    (128 | (3 << 16) | (1 << 24), dict(pol=5, interval=0.1, maxb=2)),          # ... four products, the interval ends inside the scan
+    (192 | (2 << 24), dict(pol=5)),                                            # the digitiser beside the next IF's K1
+    (192 | (2 << 24), dict(pol=2, interval=0.1, const=0, nbit=16, maxb=2)),    # ... an interval per 0.1 s (the power buffer is re-used)
+])
+def test_scan_device_lanes_give_the_same_rows(hip_lib, overlap, kw):
+    """the CU-masked lanes change WHERE and WHEN kernels run, never what they write: rows identical to the run without
+    overlap (frbch_config.overlap = 1), bit for bit"""
+    _r, _o, plain, rows = _scan_device(hip_lib, 3, 32.0, 1024, 0.27, overlap=1, **kw)
+    _r, _o, lanes, rows2 = _scan_device(hip_lib, 3, 32.0, 1024, 0.27, overlap=overlap, **kw)
+    assert rows == rows2 and np.array_equal(plain, lanes)

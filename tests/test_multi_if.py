@@ -176,3 +176,80 @@ def test_scan_device_rows_are_the_splice_of_the_per_if_rows(emu_lib, kw):
         multi_if.scan_device(chans, ptrs, nfr, 8032, 32, 0, nblocks + 1, buf.ctypes.data, rows)
     for c in chans:
         c.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the node-level scan: python -m frb_baseband_amd.scan = one rank process per GPU + the native streaming join
+# (base2fil.sh:30-67, 348-350, 404-448).  On CPU the ranks load the TEST-ONLY emulator build through FRBCH_LIB.
+# ------------------------------------------------------------------------------------------------------------------
+def _node_scan(tmp_path, emu_lib, nif, world, extra=(), drop=None, **kw):
+    from frb_baseband_amd import _lib
+    d = str(tmp_path)
+    raws = {}
+    for i in range(1, nif + 1):
+        raws[i] = synth.make_vdif(0.02, bw_mhz=16.0, nchan=32, if_index=i)
+        if i != drop:
+            raws[i].tofile(os.path.join(d, f"x_ef_no0001_IF{i}.vdif"))
+    emu = os.path.join(ROOT, "tests", "emu", "libfrbch_emu.so")
+    env = dict(os.environ, FRBCH_LIB=emu, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "frb_baseband_amd.scan", "--experiment", "x", "--st", "ef", "--scanname", "001", "--workdir", d,
+           "--outdir", d, "--nif", str(nif), "--bw", "16", "--freqLSB_0", "1340.0", "--nchan", "32", "--nsec", "0.02",
+           "--ra", "01:00:00.0", "--dec", "02:00:00.0", "--gpus", str(world), "--share-gpu"] + list(extra)
+    pr = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    return raws, pr, os.path.join(d, multi_if.ifall_name("x", "ef", "001", kw.get("pol", 2)))
+
+
+def test_node_scan_command_two_ranks_and_the_native_join(emu_lib, tmp_path):
+    raws, pr, out = _node_scan(tmp_path, emu_lib, 4, 2)
+    assert pr.returncode == 0, pr.stderr
+    got = sigproc.read_fil(out)
+    parts, want = _oracle_ifall(raws, 4, 16.0, 32, 0.02)
+    assert got.data.shape == want.shape == (parts[0].data.shape[0], 1, 128)
+    assert np.abs(got.data.astype(int) - want.astype(int)).max() <= 1 and np.count_nonzero(got.data != want) <= 2e-5 * want.size
+    assert got.header["nchans"] == 128 and got.header["fch1"] == pytest.approx(parts[0].header["fch1"])
+    assert not [f for f in os.listdir(str(tmp_path)) if f.endswith(".fil") and "IFall" not in f]   # no per-IF products
+    # the same scan on one rank: the rank writes the product itself, byte for byte the same file
+    one = open(out, "rb").read()
+    os.remove(out)
+    _r, pr1, out1 = _node_scan(tmp_path, emu_lib, 4, 1)
+    assert pr1.returncode == 0, pr1.stderr
+    assert open(out1, "rb").read() == one
+
+
+def test_node_scan_three_ranks_four_products_uneven_shares(emu_lib, tmp_path):
+    raws, pr, out = _node_scan(tmp_path, emu_lib, 5, 3, extra=("--pol", "5", "--nbit", "16", "--tscrunch", "2"), pol=5)
+    assert pr.returncode == 0, pr.stderr
+    got = sigproc.read_fil(out)
+    parts, want = _oracle_ifall(raws, 5, 16.0, 32, 0.02, pol_mode=5, nbit=16, tscrunch=2)
+    assert got.data.shape == want.shape and got.header["nifs"] == 4 and got.header["nchans"] == 160
+    _m, dscale, _v = o.digi_params(16)                                  # 16-bit codes: rounding ties are that much denser (parity_util)
+    assert np.abs(got.data.astype(int) - want.astype(int)).max() <= 1
+    assert np.count_nonzero(got.data != want) <= pu.MISMATCH_FRAC_PER_SIGMA * dscale * want.size
+
+
+def test_node_scan_a_failing_rank_fails_the_run(emu_lib, tmp_path):
+    _r, pr, out = _node_scan(tmp_path, emu_lib, 4, 2, drop=1)       # IF1's VDIF is missing: rank 1 fails
+    assert pr.returncode != 0
+    assert "rank" in pr.stderr and "failed" in pr.stderr
+
+
+def test_native_join_cuts_to_the_shortest_piece_and_checks_headers(emu_lib, tmp_path):
+    """frbch_join == multi_if.splice (the numpy restatement of sigproc splice) on files of unequal length"""
+    d = str(tmp_path)
+    pieces = []
+    for i, secs in ((1, 0.03), (2, 0.02), (3, 0.03)):
+        raw = synth.make_vdif(secs, bw_mhz=16.0, nchan=32, if_index=i)
+        with ch.Channeliser(pu.lib_cfg(emu_lib, 16.0, 32, secs, pol=4, freq_res=64), emu_lib) as c:
+            p = os.path.join(d, f"p{i}.fil")
+            open(p, "wb").write(c.channelise_bytes(raw))
+            pieces.append(p)
+    join = os.path.join(ROOT, "frb_baseband_amd", "csrc", "frbch_join")
+    out = os.path.join(d, "joined.fil")
+    pr = subprocess.run([join, out] + pieces, capture_output=True, text=True, timeout=120)
+    assert pr.returncode == 0, pr.stderr
+    assert open(out, "rb").read() == multi_if.splice(pieces)
+    with ch.Channeliser(pu.lib_cfg(emu_lib, 16.0, 32, 0.02, pol=2, freq_res=64), emu_lib) as c:
+        other = os.path.join(d, "other.fil")
+        open(other, "wb").write(c.channelise_bytes(synth.make_vdif(0.02, bw_mhz=16.0, nchan=32)))
+    pr = subprocess.run([join, out, pieces[0], other], capture_output=True, text=True, timeout=120)
+    assert pr.returncode != 0 and "differ" in pr.stderr

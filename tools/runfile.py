@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """PCIe-inclusive rate of the whole-file path (what the digifil shim does): file -> host -> HBM -> .fil on disk."""
 import os, sys, time, subprocess
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from frb_baseband_amd import synth, process_vdif as pv
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0

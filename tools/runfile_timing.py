@@ -4,7 +4,7 @@
 file and a parallel memcpy into a shared mapping of one."""
 import mmap, os, sys, threading, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from frb_baseband_amd import channeliser as ch, synth
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 10.0
 raw = synth.make_vdif(secs, bw_mhz=32.0, nchan=1024)

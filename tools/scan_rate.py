@@ -1,6 +1,6 @@
 """Host-inclusive rate of frbch_run_scan: nif IFs x secs of synthetic VDIF in tmpfs -> one IFall file (not `value`)."""
 import os, sys, time, tempfile
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from frb_baseband_amd import multi_if, synth
 nif, secs, pol = int(sys.argv[1]), float(sys.argv[2]), int(sys.argv[3])
 d = tempfile.mkdtemp(dir="/dev/shm")
