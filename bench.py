@@ -495,6 +495,42 @@ def host_inclusive(args, torch, dist, wl, rank, world):
                                "pcie": {"bound": "pcie", "achieved": round(each_way, 2), "peak": PCIE_PEAK_GBS,
                                         "unit": "GB/s in the busier direction per GPU", "frac": round(each_way / PCIE_PEAK_GBS, 4)},
                                "path": f"frbch_run_scan, {nif} IFs: {base} VDIF files -> pinned rings -> HBM (rows joined in the K2 / digitiser store addresses) -> pinned ring -> /dev/null"}
+        if world > 1 and dist is not None:
+            # the node-level scan (python -m frb_baseband_amd.scan, base2fil.sh:30-67 + 348-350 + 404-448): every rank runs its
+            # IFs through frbch_run_scan into a named FIFO, ONE native join (csrc/frbch_join, started by rank 0; it never touches
+            # a GPU) concatenates the ranks' pieces into the IFall stream while they produce
+            import subprocess
+            from frb_baseband_amd import multi_if, scan as scan_mod
+            tag = os.environ.get("MASTER_PORT", "0")
+            fifos = [os.path.join(base, f"frbch_bench_join_{tag}_rank{r}.fil") for r in range(world)]
+            chans = [ch.Channeliser(ch.new_config(**kw)) for kw in wl.cfg_kwargs]
+            try:
+                def node_scan():
+                    join = None
+                    if rank == 0:
+                        for f in fifos:
+                            if os.path.exists(f):
+                                os.remove(f)
+                            os.mkfifo(f)
+                        join = subprocess.Popen([scan_mod.JOIN_PATH, "/dev/null"] + fifos, stdout=subprocess.DEVNULL)
+                    dist.barrier()
+                    for c in chans:
+                        c.reset()
+                    multi_if.run_scan(chans, vds, fifos[rank])
+                    if join is not None and join.wait(timeout=600) != 0:
+                        raise RuntimeError("frbch_join failed")
+                    dist.barrier()
+                best = timed(node_scan)
+            finally:
+                for c in chans:
+                    c.close()
+                if rank == 0:
+                    for f in fifos:
+                        if os.path.exists(f):
+                            os.remove(f)
+            res["node_scan"] = {"value": round(wl.samples_per_step * world / best / 1e6, 1), "unit": "Msamples/s", "s_per_scan": round(best, 4),
+                                "n_gpus": world, "ifs": nif * world,
+                                "path": f"{world} ranks x frbch_run_scan ({nif} IFs each) -> {world} FIFOs -> frbch_join -> /dev/null (one IFall stream of {nif * world * wl.spec['nchan']} channels)"}
         return res
     except Exception as exc:   # a reported extra: never fail the bench for it
         res["error"] = repr(exc)

@@ -130,6 +130,8 @@ struct frbch_handle {
   size_t evnext = 0;
   uint32_t next_region = 0;        // spill region of the next batch
   uint32_t diag = 0;               // frbch_info::diag
+  uint8_t* scan_rows = nullptr;    // frbch_run_scan (first handle of the scan): the row buffer of all its IFs, kept between calls
+  size_t scan_rows_bytes = 0;
   dev_event_t quant_ev{};          // behind a digitiser that ran on the back lane (mode 2)
   bool quant_ev_made = false, quant_busy = false;
   int quant_lane_cus = 0;          // CUs of the lane the digitiser was sent to
@@ -589,6 +591,18 @@ bool launch_k1_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
 }
 bool launch_k2_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   const Plan& pl = h->pl;
+  if (pl.fast_k2_lane) {   // 2C = 64 / 128: a whole sequence per lane (pair)
+    if (p.tile_major) return false;
+    const int pmk = p.pol_mode == 2 ? 2 : (p.pol_mode >= 4 ? 4 : 0);
+    const dim3 grid((unsigned)((uint64_t)pl.r * nb * pl.fast_k2_lane / 256));
+    const size_t lds = 4 * 64 * (16 * 8 + 16);   // one transposing strip per wave
+#define FRBCH_K2L(NHV) do { if (pmk == 2) hipLaunchKernelGGL((fast::frbch_k2_lane<NHV, 2>), grid, dim3(256), lds, s, p); \
+                            else if (pmk == 4) hipLaunchKernelGGL((fast::frbch_k2_lane<NHV, 4>), grid, dim3(256), lds, s, p); \
+                            else hipLaunchKernelGGL((fast::frbch_k2_lane<NHV, 0>), grid, dim3(256), lds, s, p); } while (0)
+    if (pl.fast_k2_lane == 1) FRBCH_K2L(1); else FRBCH_K2L(2);
+#undef FRBCH_K2L
+    return true;
+  }
   if (pl.fast_k2_wave) {
     // tscrunch beyond the kernel's tile: rows of its largest tile into the scratch buffer (q), then the sums (p)
     KParams q = p;
@@ -1008,18 +1022,21 @@ int run_stats(frbch_handle* h, uint64_t rows, dev_stream_t s) {
   sp.c = pl.c;
   sp.nif = pl.nif;
   sp.flip = pl.flip;
-  sp.nchunk = (int)std::min<uint64_t>((uint64_t)h->partial_chunks, std::max<uint64_t>(1, rows / 32));
+  // narrow rows (fewer than 64 column groups): the threads of a 64-thread workgroup share the column groups and split the rows
+  const int cg = (int)(pl.ncol / 4);
+  sp.rsplit = (cg < 64 && 64 % cg == 0) ? 64 / cg : 1;
+  sp.nchunk = (int)std::min<uint64_t>((uint64_t)h->partial_chunks / sp.rsplit, std::max<uint64_t>(1, rows / (32 * sp.rsplit)));
+  if (sp.nchunk < 1) sp.nchunk = 1;
   sp.rows_per_chunk = (rows + sp.nchunk - 1) / sp.nchunk;
   sp.nchunk = (int)((rows + sp.rows_per_chunk - 1) / sp.rows_per_chunk);
   sp.cpw = stat_final_cpw(pl);
   sp.offset = h->offset;
   sp.scale = h->scale;
-  const int gx = (int)((pl.ncol + 255) / 256);
-  const int gx4 = (int)((pl.ncol / 4 + 63) / 64);
+  const int gx4 = (int)((pl.ncol / 4 * sp.rsplit + 63) / 64);
   ProfScope ps(h, s, KID_STATS, (double)rows * pl.ncol * 4.0);
   DEV_LAUNCH(frbch_stats_partial, gx4, sp.nchunk, 64, 0, s, sp);
+  sp.nchunk *= sp.rsplit;          // rows of partial sums the final reduction adds up (fixed order: deterministic)
   DEV_LAUNCH(frbch_stats_final, (int)((pl.ncol + sp.cpw - 1) / sp.cpw), 1, 256, 256 * 2 * sizeof(double), s, sp);
-  (void)gx;
   CHECK_DEV(h, dev_check_launch(), "launch stats");
   return FRBCH_OK;
 }
@@ -1614,6 +1631,12 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
       snprintf(nm, sizeof nm, "frbch_k2_wave<0,%d,%d,1>", pl.fast_k2_nw, h->cfg.pol_mode == 2 ? 2 : (h->cfg.pol_mode >= 4 ? 4 : 0));
       h->kname[KID_K2] = nm;
     }
+#ifndef FRBCH_NO_FAST
+    if (pl.fast_k2_lane) {
+      snprintf(nm, sizeof nm, "frbch_k2_lane<%d,%d>", pl.fast_k2_lane, h->cfg.pol_mode == 2 ? 2 : (h->cfg.pol_mode >= 4 ? 4 : 0));
+      h->kname[KID_K2] = nm;
+    }
+#endif
   }
 
   CHECK_DEV(h, dev_malloc((void**)&h->spill, (size_t)pl.maxb * (pl.c2 / pl.g) * pl.gs * sizeof(cf)), "hipMalloc(spill)");
@@ -1656,7 +1679,7 @@ extern "C" void frbch_close(frbch_handle* h) {
   dev_free(h->spill); dev_free(h->s_dc); dev_free(h->p0);
   dev_free(h->spill2); dev_free(h->chirp); dev_free(h->ptmp); dev_free(h->scr2);
   dev_free(h->offset); dev_free(h->scale); dev_free(h->powbuf); dev_free(h->partial);
-  dev_free(h->d_frames); dev_free(h->d_out); dev_free(h->stg); dev_free(h->d_fbad);
+  dev_free(h->d_frames); dev_free(h->d_out); dev_free(h->stg); dev_free(h->d_fbad); dev_free(h->scan_rows);
   for (int i = 0; i < 8; ++i) { dev_host_free(h->pin_in[i]); dev_host_free(h->pin_out[i]); }
   if (h->stream) dev_stream_destroy(h->stream);
   if (h->user_ev_made) dev_event_destroy(h->user_ev);
@@ -2779,8 +2802,15 @@ extern "C" int frbch_run_scan(frbch_handle* const* ifs, uint32_t nif, const char
     push_batches = std::max<uint64_t>(push_batches, kScanPushBytes / std::max<uint64_t>(1, (uint64_t)q.maxb * q.block_stride_bytes) + 2);
   }
   const uint64_t rows_cap = pl.interval_rows + std::max<uint64_t>(3, push_batches) * pl.maxb * pl.rows_per_block + 16;
-  uint8_t* d_rows = nullptr;
-  CHECK_DEV(h0, dev_malloc((void**)&d_rows, rows_cap * row_pitch), "hipMalloc(scan rows)");
+  // the scan's row buffer stays with the first handle (tens of GB for a four-product interval of 8 IFs: allocating and
+  // freeing it cost ~1 s per call, profiles/r03_scan_host_path.txt)
+  if (!h0->scan_rows || h0->scan_rows_bytes < rows_cap * row_pitch) {
+    dev_free(h0->scan_rows);
+    h0->scan_rows = nullptr;
+    h0->scan_rows_bytes = rows_cap * row_pitch;
+    CHECK_DEV(h0, dev_malloc((void**)&h0->scan_rows, h0->scan_rows_bytes), "hipMalloc(scan rows)");
+  }
+  uint8_t* const d_rows = h0->scan_rows;
   std::vector<FILE*> in(nif, nullptr);
   int fd = -1, rc = FRBCH_OK;
   uint8_t* stage = nullptr;            // pinned host staging of finished rows
@@ -2789,7 +2819,6 @@ extern "C" int frbch_run_scan(frbch_handle* const* ifs, uint32_t nif, const char
     for (FILE* f : in) if (f) fclose(f);
     if (fd >= 0) close(fd);
     dev_host_free(stage);
-    dev_free(d_rows);
     for (uint32_t i = 0; i < nif; ++i) { ifs[i]->sink = nullptr; ifs[i]->out_pitch = 0; }
   };
   for (uint32_t i = 0; i < nif && !rc; ++i) {

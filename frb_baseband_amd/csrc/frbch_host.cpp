@@ -295,6 +295,15 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
     if (!pl->fast_k2_wave || !(pl->fast_k2_log2m || pl->fast_k2_m1)) pl->k2_two_stage = 0;
   }
 
+  // few channels (2C = 64 / 128: the 32 / 64 channels per IF of the online chain, submit_job.py:74-105): one lane (pair)
+  // keeps a whole across-branch sequence in registers (frbch_k2_lane); reads the slab layout of 16-branch groups the
+  // R = 512 wave K1 (or the generic K1 in its place) writes
+  pl->fast_k2_lane = 0;
+  if (!(cfg.flags & 2u) && !pl->coherent && (pl->c2 == 64 || pl->c2 == 128) && pl->g == 16 && !pl->fast_k2_log2m && !pl->fast_k2_m1) {
+    const int nh = pl->c2 / 64;
+    if (pl->tscr <= 64 / nh && ((int)r * nh) % 256 == 0) pl->fast_k2_lane = nh;
+  }
+
   // R = 2048, flag bit 24: the split K1 (bin-parity halves, 16 independent waves per CU) instead of the paired-branch wave
   // K1 whenever frbch_k0_stage has corner-turned the batch (measured slower: 1.76 vs 1.54 ms)
   pl->fast_k1_split = 0;

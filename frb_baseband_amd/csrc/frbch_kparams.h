@@ -102,6 +102,8 @@ struct StatParams {
   uint64_t rows;            // rows that enter the statistics
   uint64_t rows_per_chunk;
   int ncol, c, nif, flip, nchunk;
+  int rsplit;               // frbch_stats_partial: threads sharing one column group (rows interleaved), > 1 for narrow rows; the
+                            // final reduction then runs over nchunk = chunks x rsplit rows of partial sums
   int cpw;                  // frbch_stats_final: columns per workgroup (8 = whole lines of the partial sums; 2 when there are few columns)
   float* offset;            // [nif][C] input channel order
   float* scale;

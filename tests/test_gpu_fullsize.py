@@ -216,3 +216,30 @@ def test_direct_scan_on_device_equals_spliced_per_if_runs(tmp_path):
                    ra="01:58:00.75", dec="65:43:00.3")
     want = sigproc.read_fil(o.channelise(raws[4], cfg)).data
     pu.check_code_arrays(want, ga.data[:, :, :1024], cfg)               # identical except at rounding ties
+
+
+def test_node_scan_command_two_ranks_on_one_card(tmp_path):
+    """python -m frb_baseband_amd.scan (base2fil.sh:30-67, 348-350, 404-448 in one command): two rank processes (rehearsal:
+    both on GPU 0), 2 IFs each through frbch_run_scan into their FIFOs, the native join writes the IFall file; every IF's
+    columns against the oracle.  Config-2 shape, 2 blocks per IF."""
+    import subprocess
+    import sys
+    d = str(tmp_path)
+    raws = {}
+    for i in (1, 2, 3, 4):
+        raws[i] = synth.make_vdif(0.14, bw_mhz=32.0, nchan=1024, if_index=i)
+        raws[i].tofile(os.path.join(d, f"x_ef_no0001_IF{i}.vdif"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "frb_baseband_amd.scan", "--experiment", "x", "--st", "ef", "--scanname", "001", "--workdir", d,
+           "--outdir", d, "--nif", "4", "--bw", "32", "--freqLSB_0", "1340.0", "--nchan", "1024", "--nsec", "0.14", "--source", "R3",
+           "--ra", "01:58:00.75", "--dec", "65:43:00.3", "--gpus", "2", "--share-gpu"]
+    pr = subprocess.run(cmd, cwd=root, env=dict(os.environ, PYTHONPATH=root), capture_output=True, text=True, timeout=600)
+    assert pr.returncode == 0, pr.stderr
+    got = sigproc.read_fil(os.path.join(d, multi_if.ifall_name("x", "ef", "001", 2)))
+    assert got.header["nchans"] == 4096
+    for col, i in enumerate((4, 3, 2, 1)):
+        plan = multi_if.plan_ifs(4, 1340.0, 32.0)[i - 1]
+        cfg = o.Config(bw_mhz=32.0 if plan.sideband == "u" else -32.0, freq_mhz=plan.freq_mhz, nchan=1024, total_s=0.14,
+                       source="R3", ra="01:58:00.75", dec="65:43:00.3")
+        want = sigproc.read_fil(o.channelise(raws[i], cfg)).data
+        pu.check_code_arrays(want, got.data[:, :, col * 1024:(col + 1) * 1024], cfg)

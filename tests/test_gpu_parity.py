@@ -103,6 +103,18 @@ CASES = [
     (16.0, 128, 0.05, dict(pol=5, tscr=8, nbit=-32)),        # 2C = 256 wave K2
     (64.0, 4096, 0.55, dict(pol=5, tscr=2)),                  # M = 32
     (-32.0, 512, 0.15, dict(dm=26.7, coherent=1, freq=350.0, pol=5, tscr=2)),   # K3 (register passes)
+    # few channels per IF (the online chain's 32 / 64, submit_job.py:74-105; R = 512 as process_vdif.py:162 says): wave K1 (M = 2) +
+    # frbch_k2_lane (a whole 64-point across-branch sequence per lane; 2C = 128: per lane pair)
+    (16.0, 32, 0.02, {}),
+    (-16.0, 32, 0.02, dict(pol=5, tscr=4, nbit=16)),
+    (32.0, 32, 0.02, dict(pol=4, nbit=2)),
+    (16.0, 32, 0.02, dict(pol=3, nbit=-32, tscr=64)),
+    (16.0, 32, 0.02, dict(pol=0, interval=0.004, const=0, maxb=5)),
+    (32.0, 64, 0.02, {}),
+    (-32.0, 64, 0.02, dict(pol=4, tscr=2)),
+    (16.0, 64, 0.02, dict(pol=5, nbit=-32, tscr=32)),
+    (16.0, 64, 0.02, dict(pol=1, nbit=2, tscr=8, interval=0.005)),
+    (16.0, 64, 0.02, dict(tscr=64)),                          # beyond the lane pair's 32 samples: generic K2
 ]
 
 
@@ -133,3 +145,14 @@ def test_power_tap_matches_oracle(hip_lib):
     err = np.abs(got - want).max() / scale
     print("max |P - P_oracle| / mean(PP+QQ) =", err)
     assert err <= pu.POWER_RTOL, err
+
+
+@pytest.mark.parametrize("nchan,want", [(32, "frbch_k2_lane<1,2>"), (64, "frbch_k2_lane<2,2>")])
+def test_few_channels_run_on_the_lane_kernel(hip_lib, nchan, want):
+    from frb_baseband_amd import channeliser as ch, synth
+    raw = synth.make_vdif(0.02, bw_mhz=16.0, nchan=nchan)
+    with ch.Channeliser(pu.lib_cfg(hip_lib, 16.0, nchan, 0.02), hip_lib) as c:
+        c.set_profiling(True)
+        c.channelise_bytes(raw)
+        names = {k for k, v in c.get_timing().items() if v["launches"]}
+    assert want in names and any(n.startswith("frbch_k1_wave<1") for n in names), names
