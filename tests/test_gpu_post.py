@@ -154,3 +154,62 @@ def test_config5_as_stated(hip_lib, tmp_path):
     assert snr > 20
     assert profile[(peak + 2) % 128] - off.mean() < 0.15 * (profile[peak] - off.mean())
     assert profile[(peak - 2) % 128] - off.mean() < 0.15 * (profile[peak] - off.mean())
+
+
+@pytest.mark.parametrize("nbits,zerodm,clip", [(8, True, 5.0), (16, False, 0.0), (32, True, 4.0)])
+def test_dm_range_on_the_tiled_kernel_matches_oracle(hip_lib, nbits, zerodm, clip):
+    """prepsubband's DM range (process_vdif.py:202-229: -lodm / -numdms / -dmstep): 64 DMs from the same rows through the
+    LDS-tiled kernel (DM groups of 8, 64-byte channel tiles) -- bit-identical to the oracle, float rows included (double
+    sums in ascending channel order), with clipped samples and the zero-DM term staged in the LDS as well"""
+    x = pulse_train_rows(12000, HDR1K).astype(np.float64)
+    x[5000:5005] += 90
+    data = x.astype(np.uint8) if nbits == 8 else ((x * 55).astype(np.uint16) if nbits == 16 else (x * 0.37 - 3.0).astype(np.float32))
+    dms = post.dm_list(20.0, 83.0, 1.0)
+    assert len(dms) == 64
+    got, nclip = post.dedisperse(as_fil(data, HDR1K, nbits), dms, zerodm=zerodm, clip=clip, lib=hip_lib)
+    want, nclip2 = po.dedisperse(data, fch1=HDR1K["fch1"], foff=HDR1K["foff"], tsamp=HDR1K["tsamp"], dms=dms, zerodm=zerodm,
+                                 clip=clip, integer=nbits != 32)
+    assert nclip == nclip2
+    assert np.array_equal(got, want)
+
+
+def test_dm_range_device_time_at_full_size(hip_lib):
+    """320 MB of rows (10 s x 1024 channels, 8 bit) x 64 DMs, rows resident in HBM: device time of frbch_dedisperse_device
+    (< 60 ms) and conservation of the total (every output sample is a sum of nchan input samples)"""
+    import ctypes as C
+    from frb_baseband_amd import _lib
+    from tests.hipmem import DeviceBuffer
+    rng = np.random.default_rng(11)
+    nrows, nchan = 312500, 1024
+    data = rng.integers(100, 156, size=(nrows, nchan), dtype=np.uint8)
+    fil = as_fil(data, HDR1K, 8)
+    dms = np.asarray(post.dm_list(300.0, 363.0, 1.0), dtype=np.float64)
+    desc = post.fil_desc(fil.header)
+    nout = hip_lib.frbch_dedisperse_nout(C.byref(desc), nrows, dms.ctypes.data, len(dms))
+    assert nout > 0
+    d_rows = DeviceBuffer.from_numpy(data)
+    d_out = DeviceBuffer(len(dms) * nout * 4)
+    err = C.create_string_buffer(256)
+    nclip = C.c_uint64(0)
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        rc = hip_lib.frbch_dedisperse_device(C.byref(desc), d_rows.ptr, nrows, dms.ctypes.data, len(dms), 0, 0.0, 0, d_out.ptr, nout,
+                                             C.byref(nclip), err, len(err))
+        times.append(time.perf_counter() - t0)
+        assert rc == 0, err.value
+    y = d_out.to_numpy(np.float32).reshape(len(dms), nout)
+    # every series: sum over channels of shifted rows -- its mean is nchan x the mean sample (to the noise of the shifts)
+    assert abs(y.mean() / nchan - data.mean()) < 0.05
+    # spot check against the definition for a few (dm, t)
+    from oracle import post_oracle
+    for i in (0, 31, 63):
+        dly = post_oracle.delays_samples(HDR1K["fch1"], HDR1K["foff"], nchan, HDR1K["tsamp"], float(dms[i]))
+        for t in (0, 1234, nout - 1):
+            assert y[i, t] == float(data[t + dly, np.arange(nchan)].astype(np.int64).sum())
+    stats = {"rows": nrows, "nchan": nchan, "ndm": len(dms), "call_s_best": min(times), "call_s_all": times}
+    print("DEDISP-RANGE " + json.dumps(stats))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/post_dm_range.json", "w") as f:
+        json.dump(stats, f)
+    assert min(times) < 0.060, stats
