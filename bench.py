@@ -495,6 +495,55 @@ def host_inclusive(args, torch, dist, wl, rank, world):
                                "pcie": {"bound": "pcie", "achieved": round(each_way, 2), "peak": PCIE_PEAK_GBS,
                                         "unit": "GB/s in the busier direction per GPU", "frac": round(each_way / PCIE_PEAK_GBS, 4)},
                                "path": f"frbch_run_scan, {nif} IFs: {base} VDIF files -> pinned rings -> HBM (rows joined in the K2 / digitiser store addresses) -> pinned ring -> /dev/null"}
+        if world == 1:
+            # A scan of minutes, as the reference records them (frb.conf `lengths`): 60 s of ONE IF as Stokes I (-d1); the first
+            # 10-s rescale interval is buffered, after it input, transform and output stream batch by batch.  Into /dev/null
+            # (the library's own pipeline) and into a named FIFO drained by a reader (base2fil.sh:348-350: what digifil writes
+            # into and splice reads from).
+            import threading
+            spec60 = dict(wl.spec, nif=1, pol=2, seconds=60.0)
+            fr60, nfr60 = synth_frames_device(torch, wl.out.device, 60.0, spec60["bw"], spec60["nchan"], if_index=99)
+            vd60 = os.path.join(base, f"frbch_bench_{os.getpid()}_60s.vdif")
+            fifo = os.path.join(base, f"frbch_bench_{os.getpid()}_60s.fifo")
+            try:
+                fr60[: nfr60 * 8032].cpu().numpy().tofile(vd60)
+                del fr60
+                kw60 = dict(wl.cfg_kwargs[0], pol_mode=2, total_s=60.0, bw_mhz=spec60["bw"])
+                samples60 = nfr60 * 8000 * 2
+                os.mkfifo(fifo)
+                with ch.Channeliser(ch.new_config(**kw60)) as c:
+                    def to_null():
+                        c.reset()
+                        c.run_file(vd60, "/dev/null")
+
+                    def to_fifo():
+                        c.reset()
+
+                        def drain():
+                            with open(fifo, "rb", buffering=0) as f:
+                                buf = bytearray(1 << 24)
+                                while f.readinto(buf):
+                                    pass
+                        th = threading.Thread(target=drain)
+                        th.start()
+                        c.run_file(vd60, fifo)
+                        th.join()
+                    t_null = timed(to_null)
+                    t_fifo = timed(to_fifo)
+                out60 = samples60 // 2       # 8-bit Stokes I: one byte per two dual-pol samples
+                res["long_scan"] = {
+                    "scan": f"60 s of one {spec60['bw']:g} MHz IF -> {spec60['nchan']}-ch Stokes I 8 bit (-c -I 10: first interval buffered, then streamed)",
+                    "bytes_in": os.path.getsize(vd60), "bytes_out": out60,
+                    "dev_null": {"value": round(samples60 / t_null / 1e6, 1), "unit": "Msamples/s", "s_per_scan": round(t_null, 4),
+                                 "pcie_frac_each_way": round(out60 / t_null / 1e9 / PCIE_PEAK_GBS, 4)},
+                    "fifo_drained": {"value": round(samples60 / t_fifo / 1e6, 1), "unit": "Msamples/s", "s_per_scan": round(t_fifo, 4),
+                                     "pcie_frac_each_way": round(out60 / t_fifo / 1e9 / PCIE_PEAK_GBS, 4)}}
+            finally:
+                for f in (vd60, fifo):
+                    try:
+                        os.remove(f)
+                    except OSError:
+                        pass
         if world > 1 and dist is not None:
             # the node-level scan (python -m frb_baseband_amd.scan, base2fil.sh:30-67 + 348-350 + 404-448): every rank runs its
             # IFs through frbch_run_scan into a named FIFO, ONE native join (csrc/frbch_join, started by rank 0; it never touches

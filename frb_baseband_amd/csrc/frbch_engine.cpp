@@ -1164,6 +1164,14 @@ Lanes* get_lanes(int device, int ncu_front) {
   Lanes* ln = new Lanes();
   g_lanes.push_back({{device, ncu_front}, ln});
   ln->ncu = dev_cu_count(device);
+  if (ncu_front >= ln->ncu && ln->ncu > 0) {
+    // no partition: plain streams.  Kernels of the two lanes share every CU as far as its registers, LDS and wave slots go
+    // (the digitiser's 4-wave workgroups fit beside the wave K1's eight 216-register waves: one per CU)
+    if (dev_stream_create(&ln->f) != 0 || dev_stream_create(&ln->b) != 0 || dev_stream_create(&ln->b2) != 0) return nullptr;
+    ln->ncu_f = ln->ncu;
+    ln->ok = true;
+    return ln;
+  }
   if (ln->ncu < 32 || ln->ncu % 8 || ncu_front < 8 || ncu_front > ln->ncu - 8 || ncu_front % 8) return nullptr;
   const uint32_t words = (uint32_t)((ln->ncu + 31) / 32);
   std::vector<uint32_t> mf(words, 0u), mb(words, 0u);
@@ -1285,7 +1293,7 @@ void chain_back_done(Chain* c, dev_stream_t sb) {
 dev_stream_t chain_quant_stream(Chain* c, dev_stream_t s, int* ncu) {
   if (!c || !c->ln || c->mode != 2 || c->fronts >= c->stages_total) return s;
   const dev_stream_t sq = c->ln->b;
-  *ncu = c->ln->ncu - c->ln->ncu_f;
+  *ncu = c->ln->ncu_f >= c->ln->ncu ? c->ln->ncu : c->ln->ncu - c->ln->ncu_f;
   if (!c->b_rooted) {
     (void)dev_stream_wait(sq, c->ev_entry);
     c->b_rooted = true;
