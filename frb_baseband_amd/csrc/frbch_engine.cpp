@@ -636,6 +636,22 @@ bool launch_k2_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
     }
     return true;
   }
+  if (pl.k2_two_stage && pl.fast_k2_log2m == 5) {   // barrier K2, four products: two-sample rows into the scratch buffer, then the sums
+    KParams q = p;
+    q.tscr = pl.k2_stage1_tscr;
+    q.out_mode = FRBCH_OUT_FLOAT_POWER;
+    q.power_out = h->scr2;
+    q.row0 = 0;
+    q.stat_partial = nullptr;
+    hipLaunchKernelGGL((fast::frbch_k2_fast<5, 1024>), dim3(pl.r / 2, nb), dim3(1024), pl.k2_fast_lds, s, q);
+    p.scr_in = h->scr2;
+    p.scr_fact = (uint32_t)pl.k2_two_stage;
+    p.scr_rows = (uint64_t)nb * pl.rows_per_block;
+    p.stat_partial = nullptr;
+    const uint64_t groups = p.scr_rows * (uint64_t)(pl.ncol / 4);
+    hipLaunchKernelGGL(fast::frbch_k2_scrunch, dim3((unsigned)std::min<uint64_t>((groups + 255) / 256, 8192)), dim3(256), 0, s, p);
+    return true;
+  }
   switch (pl.fast_k2_log2m) {
     case 1: launch_k2_fast_t<1>(pl, p, nb, s); break;
     case 2: launch_k2_fast_t<2>(pl, p, nb, s); break;

@@ -285,6 +285,14 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
     const size_t seq = (size_t)pl->c2 + pl->c2 / 8 + ((m == 32 && !wave) ? 0 : 8);
     const size_t lds = (size_t)tt * seq * 8 + (walk ? (size_t)pl->c * 4 : 0) +   // + the row of sub-tile sums
                        ((m == 32 && (pl->fast_k2_nt == 512 || wave)) ? 4096 : 0);   // + the radix-32 pass's twiddles (single-sample K2)
+    // 2C = 8192, four products, tscrunch > 2 (the IQUV spelling of config 4's `-t 8`): the barrier K2 writes rows of its
+    // two-sample tile into the scratch buffer and frbch_k2_scrunch adds them up (was: the generic K2, 3x slower)
+    bool barrier_two_stage = false;
+    if (m == 32 && !wave && pl->nif == 4 && pl->tscr > 2 && pl->tscr % 2 == 0 && pl->tscr <= (int)r && pl->fast_k1_log2m == 5) {
+      pl->k2_two_stage = pl->tscr / 2;
+      pl->k2_stage1_tscr = 2;
+      barrier_two_stage = true;
+    }
     if (tt >= 1 && (pl->tscr <= tt || walk || pl->k2_two_stage) && tt <= (int)r && (size_t)tt * pl->ncol * 4 <= lds && lds <= lds_limit &&
         (tt * pl->g) % 2 == 0 && (m > 1 || wave)) {   // 2C = 256 (radix 16 x 16): wave-private kernel only
       pl->fast_k2_log2m = ilog2(m);
@@ -292,7 +300,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
       pl->fast_k2_wave = wave ? 1 : 0;
       pl->k2_fast_lds = lds;
     }
-    if (!pl->fast_k2_wave || !(pl->fast_k2_log2m || pl->fast_k2_m1)) pl->k2_two_stage = 0;
+    if ((!pl->fast_k2_wave && !barrier_two_stage) || !(pl->fast_k2_log2m || pl->fast_k2_m1)) pl->k2_two_stage = 0;
   }
 
   // few channels (2C = 64 / 128: the 32 / 64 channels per IF of the online chain, submit_job.py:74-105): one lane (pair)
@@ -381,7 +389,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
     // into EQUAL batches (measured, 152-block scan: 64 + 64 + 24 blocks 3.60 ms per step, 3 x 51 3.61 ms, 76 + 76
     // 3.48 ms, one batch of 152 3.40-3.47 ms).
     const uint64_t spill_per_block = pl->n * 8 * (pl->coherent ? 2 : 1);
-    maxb = (uint32_t)std::max<uint64_t>(1, ((cfg.pol_mode >= 4 ? 4096ull : 8192ull) << 20) / spill_per_block);
+    maxb = (uint32_t)std::max<uint64_t>(1, ((cfg.pol_mode >= 4 ? 6144ull : 8192ull) << 20) / spill_per_block);   // (6 GiB: a 10-s scan of a 32 MHz IF, 152 blocks, is ONE batch with four products too)
     if (maxb > 256) maxb = 256;
   }
   if (maxb > 32768) maxb = 32768;

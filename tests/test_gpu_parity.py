@@ -94,7 +94,9 @@ CASES = [
     (64.0, 4096, 0.55, dict(flags=8)),                        # -t 1 on the barrier K2 (frbch_k2_fast<5,512>)
     (64.0, 4096, 0.55, dict(flags=1 << 21, tscr=2)),          # M = 32 with the slab layout of the spill instead of chunks of eight time samples
     (64.0, 4096, 0.55, dict(pol=4, tscr=2, nbit=16)),         # M = 32, coherency products
-    (64.0, 4096, 0.55, dict(pol=4, tscr=4)),                  # four products and tscrunch > 2: generic K2 behind the M = 32 K1
+    (64.0, 4096, 0.55, dict(pol=4, tscr=4)),                  # four products and tscrunch > 2: barrier K2 (two-sample rows) + frbch_k2_scrunch (round 3; generic K2 before)
+    (-64.0, 4096, 0.55, dict(pol=5, tscr=8, nbit=16)),        # ... the IQUV spelling of config 4's `-t 8`
+    (64.0, 4096, 1.1, dict(pol=4, tscr=8, interval=0.6, maxb=1)),   # ... the rescale interval ends inside the scan, one block per launch
     # Stokes I,Q,U,V (pol_mode 5, the `-d4 -iquv` extension; north_star "IQUV formation") through every K2 family
     (32.0, 1024, 0.14, dict(pol=5)),                         # wave K2, MSTAT instantiation while the interval is measured
     (-32.0, 1024, 0.14, dict(pol=5, tscr=2, nbit=16)),
