@@ -163,6 +163,7 @@ def build_parser():
     ap.add_argument("--host-runs", type=int, default=3, help="timed passes of the host-inclusive leg")
     ap.add_argument("--no-traffic", action="store_true", help="skip the live PMC passes (roofline.traffic = null)")
     ap.add_argument("--no-configs", action="store_true", help="skip the short runs of the other BASELINE configurations")
+    ap.add_argument("--no-steady", action="store_true", help="skip the steady-state extra (profiler runs: only the timed workload's launches)")
     ap.add_argument("--config-steps", type=int, default=5)
     ap.add_argument("--flags", type=int, default=0, help="kernel-selection flags of frbch_config (see include/frbch.h)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo with --share-gpu)")
@@ -401,13 +402,17 @@ class Workload:
         torch.cuda.synchronize()
         return self.samples_per_step * steps / (time.perf_counter() - t1) / 1e6
 
-    def close(self):
+    def release_device(self):
+        """handles, frames and row buffer freed (geometry and configuration stay readable)"""
         for c in self.chans:
             c.close()
         self.chans = []
         self.out = None
         self.frames = []
         self.torch.cuda.empty_cache()
+
+    def close(self):
+        self.release_device()
 
     def describe(self, world):
         sp, info = self.spec, self.info
@@ -435,7 +440,7 @@ def host_inclusive(args, torch, dist, wl, rank, world):
     one call) into /dev/null (a sink that does not copy: the library's own pipeline) ."""
     ch = wl.ch
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
-    nif = wl.spec["nif"]
+    nif = wl.spec["nif"] if world == 1 else min(wl.spec["nif"], 2)    # (N ranks share one host: two IFs per rank in this leg)
     vds = [os.path.join(base, f"frbch_bench_{os.getpid()}_r{rank}_if{i}.vdif") for i in range(nif)]
     fil = vds[0].replace(".vdif", ".fil")
     res = {}
@@ -443,7 +448,9 @@ def host_inclusive(args, torch, dist, wl, rank, world):
         for i in range(nif):
             wl.frames[i][: wl.nfr * 8032].cpu().numpy().tofile(vds[i])
         in_bytes = os.path.getsize(vds[0])
-        per_if = wl.samples_per_step // nif
+        rows_total, row_bytes_if, dev_out = wl.rows, wl.info.row_bytes, wl.out.device
+        wl.release_device()      # the timed workload's handles and buffers go: the legs below open their own (8 x ~15 GB with four products)
+        per_if = wl.samples_per_step // wl.spec["nif"]
 
         def timed(fn):
             times = []
@@ -454,7 +461,7 @@ def host_inclusive(args, torch, dist, wl, rank, world):
                 fn()
                 dt = time.perf_counter() - t0
                 if dist is not None:
-                    t = torch.tensor([dt], dtype=torch.float64, device=wl.out.device if args.backend == "nccl" else "cpu")
+                    t = torch.tensor([dt], dtype=torch.float64, device=dev_out if args.backend == "nccl" else "cpu")
                     dist.all_reduce(t, op=dist.ReduceOp.MAX)
                     dt = float(t.item())
                 if i:
@@ -478,7 +485,7 @@ def host_inclusive(args, torch, dist, wl, rank, world):
                            "path": f"frbch_run_file, one IF: {base} VDIF -> pinned ring -> HBM -> pinned ring -> {base} .fil, median of {args.host_runs} scans after one untimed"}
         if nif > 1:
             from frb_baseband_amd import multi_if
-            chans = [ch.Channeliser(ch.new_config(**kw)) for kw in wl.cfg_kwargs]
+            chans = [ch.Channeliser(ch.new_config(**kw)) for kw in wl.cfg_kwargs[:nif]]
             try:
                 def scan():
                     for c in chans:
@@ -488,9 +495,9 @@ def host_inclusive(args, torch, dist, wl, rank, world):
             finally:
                 for c in chans:
                     c.close()
-            out_total = wl.rows * wl.row_pitch
+            out_total = rows_total * row_bytes_if * nif
             each_way = max(in_bytes * nif, out_total) / best / 1e9
-            res["run_scan"] = {"value": round(wl.samples_per_step * world / best / 1e6, 1), "unit": "Msamples/s", "s_per_scan": round(best, 4),
+            res["run_scan"] = {"value": round(per_if * nif * world / best / 1e6, 1), "unit": "Msamples/s", "s_per_scan": round(best, 4),
                                "bytes_in": in_bytes * nif, "bytes_out": out_total,
                                "pcie": {"bound": "pcie", "achieved": round(each_way, 2), "peak": PCIE_PEAK_GBS,
                                         "unit": "GB/s in the busier direction per GPU", "frac": round(each_way / PCIE_PEAK_GBS, 4)},
@@ -502,7 +509,7 @@ def host_inclusive(args, torch, dist, wl, rank, world):
             # into and splice reads from).
             import threading
             spec60 = dict(wl.spec, nif=1, pol=2, seconds=60.0)
-            fr60, nfr60 = synth_frames_device(torch, wl.out.device, 60.0, spec60["bw"], spec60["nchan"], if_index=99)
+            fr60, nfr60 = synth_frames_device(torch, dev_out, 60.0, spec60["bw"], spec60["nchan"], if_index=99)
             vd60 = os.path.join(base, f"frbch_bench_{os.getpid()}_60s.vdif")
             fifo = os.path.join(base, f"frbch_bench_{os.getpid()}_60s.fifo")
             try:
@@ -552,7 +559,7 @@ def host_inclusive(args, torch, dist, wl, rank, world):
             from frb_baseband_amd import multi_if, scan as scan_mod
             tag = os.environ.get("MASTER_PORT", "0")
             fifos = [os.path.join(base, f"frbch_bench_join_{tag}_rank{r}.fil") for r in range(world)]
-            chans = [ch.Channeliser(ch.new_config(**kw)) for kw in wl.cfg_kwargs]
+            chans = [ch.Channeliser(ch.new_config(**kw)) for kw in wl.cfg_kwargs[:nif]]
             try:
                 def node_scan():
                     join = None
@@ -577,7 +584,7 @@ def host_inclusive(args, torch, dist, wl, rank, world):
                     for f in fifos:
                         if os.path.exists(f):
                             os.remove(f)
-            res["node_scan"] = {"value": round(wl.samples_per_step * world / best / 1e6, 1), "unit": "Msamples/s", "s_per_scan": round(best, 4),
+            res["node_scan"] = {"value": round(per_if * nif * world / best / 1e6, 1), "unit": "Msamples/s", "s_per_scan": round(best, 4),
                                 "n_gpus": world, "ifs": nif * world,
                                 "path": f"{world} ranks x frbch_run_scan ({nif} IFs each) -> {world} FIFOs -> frbch_join -> /dev/null (one IFall stream of {nif * world * wl.spec['nchan']} channels)"}
         return res
@@ -608,7 +615,7 @@ def main():
     # live PMC passes first: the children must start before this process initialises the GPU
     live_traffic = None
     if world == 1 and not args.no_traffic and not args.pmc_child:
-        live_traffic = collect_traffic(argv + ["--steps", "1", "--warmup", "1", "--no-cpu", "--no-host", "--no-traffic", "--no-configs"])
+        live_traffic = collect_traffic(argv + ["--steps", "1", "--warmup", "1", "--no-cpu", "--no-host", "--no-traffic", "--no-configs", "--no-steady"])
     if args.pmc_child:
         args.steps, args.warmup, args.no_cpu, args.no_host, args.no_configs = 1, 1, True, True, True
 
@@ -641,7 +648,7 @@ def main():
     if args.pmc_child:
         wl.close()
         return
-    steady = wl.steady_state(args.steps)
+    steady = wl.steady_state(args.steps) if not args.no_steady else 0.0
     samples_per_step, nblocks, nif = wl.samples_per_step, wl.nblocks, spec["nif"]
     workload_text = wl.describe(world)
     host = None

@@ -389,7 +389,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
     // into EQUAL batches (measured, 152-block scan: 64 + 64 + 24 blocks 3.60 ms per step, 3 x 51 3.61 ms, 76 + 76
     // 3.48 ms, one batch of 152 3.40-3.47 ms).
     const uint64_t spill_per_block = pl->n * 8 * (pl->coherent ? 2 : 1);
-    maxb = (uint32_t)std::max<uint64_t>(1, ((cfg.pol_mode >= 4 ? 6144ull : 8192ull) << 20) / spill_per_block);   // (6 GiB: a 10-s scan of a 32 MHz IF, 152 blocks, is ONE batch with four products too)
+    maxb = (uint32_t)std::max<uint64_t>(1, ((cfg.pol_mode >= 4 ? 4096ull : 8192ull) << 20) / spill_per_block);   // (one batch of 152 blocks instead of 2 x 76 with four products measured the same, 130.1 vs 130.5 Gsamples/s: the memory is better kept)
     if (maxb > 256) maxb = 256;
   }
   if (maxb > 32768) maxb = 32768;

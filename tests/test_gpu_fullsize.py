@@ -243,3 +243,104 @@ def test_node_scan_command_two_ranks_on_one_card(tmp_path):
                        source="R3", ra="01:58:00.75", dec="65:43:00.3")
         want = sigproc.read_fil(o.channelise(raws[i], cfg)).data
         pu.check_code_arrays(want, got.data[:, :, col * 1024:(col + 1) * 1024], cfg)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[2] / [3] at full length (10 s per IF) through size-independent properties (configurations 3 and
+# 4 were oracle-checked at 2 blocks only)
+# ------------------------------------------------------------------------------------------------------------------
+def test_config3_full_length_scan_properties(hip_lib, ten_seconds):
+    """10 s x IQUV x 3 IFs through frbch_scan_device (the bench's call, 152 blocks per IF):
+    (1) every IF's columns of the scan's row buffer are bit-identical to that IF channelised alone (packed rows),
+    (2) run-to-run bit identical, (3) the frozen-scale path (K2 digitises) reproduces the buffered first interval,
+    (4) Stokes identity: every (time sample, channel) is ONE Jones vector, so I^2 = Q^2 + U^2 + V^2 to fp32 rounding."""
+    raws = [ten_seconds, synth.make_vdif(10.0, bw_mhz=32.0, nchan=1024, if_index=2), synth.make_vdif(10.0, bw_mhz=32.0, nchan=1024, if_index=3)]
+    bufs = [DeviceBuffer.from_numpy(r) for r in raws]
+    nfr = raws[0].size // 8032
+    chans = [ch.Channeliser(pu.lib_cfg(hip_lib, -32.0 if i % 2 else 32.0, 1024, 10.0, pol=5), hip_lib) for i in range(3)]
+    info = chans[0].info
+    nblocks = (nfr * 8000) // info.block_payload_bytes
+    assert nblocks == 152
+    rows = nblocks * info.rows_per_block
+    out = DeviceBuffer(rows * 3 * info.row_bytes)
+    scans = []
+    for _ in range(2):
+        for c in chans:
+            c.reset()
+        assert multi_if.scan_device(chans, [b.ptr.value for b in bufs], nfr, 8032, 32, 0, nblocks, out.ptr.value, rows) == rows
+        scans.append(out.to_numpy(np.uint8).reshape(rows, 4, 3 * 1024))
+    assert np.array_equal(scans[0], scans[1])                                  # (2)
+    resc = [c.get_rescale() for c in chans]
+    for c, (off, sc) in zip(chans, resc):
+        c.reset()
+        c.set_rescale(off, sc)
+    assert multi_if.scan_device(chans, [b.ptr.value for b in bufs], nfr, 8032, 32, 0, nblocks, out.ptr.value, rows, flush=False) == rows
+    assert np.array_equal(out.to_numpy(np.uint8).reshape(scans[0].shape), scans[0])   # (3)
+    single = DeviceBuffer(rows * info.row_bytes)
+    for i, c in enumerate(chans):                                              # (1)
+        c.reset()
+        r1 = c.process_device(bufs[i].ptr.value, nfr, 8032, 32, 0, nblocks, single.ptr.value, single.nbytes)
+        r1 += c.flush_device(single.ptr.value + r1 * info.row_bytes, single.nbytes - r1 * info.row_bytes)
+        assert r1 == rows
+        assert np.array_equal(single.to_numpy(np.uint8).reshape(rows, 4, 1024), scans[0][:, :, i * 1024:(i + 1) * 1024])
+    d = scans[0].astype(np.float64)
+    assert abs(d[:, 0].mean() - 127.5) < 0.6 and abs(d[:, 0].std() - 127.5 / 6) < 1.5       # I: mean / sigma of the digitiser
+    # (4) on the float products of 19 blocks
+    c = chans[0]
+    c.reset()
+    nb = 19
+    pw = DeviceBuffer(nb * info.rows_per_block * 4 * 1024 * 4)
+    c.power_device(bufs[0].ptr.value, nfr, 8032, 32, 40 * info.block_payload_bytes, nb, pw.ptr.value, pw.nbytes)
+    p = pw.to_numpy(np.float32).reshape(-1, 4, 1024).astype(np.float64)
+    lhs, rhs = p[:, 0] ** 2, p[:, 1] ** 2 + p[:, 2] ** 2 + p[:, 3] ** 2
+    assert np.abs(lhs - rhs).max() <= 4e-6 * lhs.max()
+    assert np.all(p[:, 0] >= 0)
+    for c in chans:
+        c.close()
+
+
+def test_config4_full_length_parseval_and_determinism(hip_lib):
+    """BASELINE configs[3], one IF of a GPU's share at full length: 10 s x 64 MHz -> 4096 channels (19 blocks of 2^26
+    samples): Parseval per block on the float power (as test_parseval_every_block_full_size), `-t 8` codes run-to-run
+    identical and equal between the buffered first interval and the frozen-scale path."""
+    bw, nchan, r = 64.0, 4096, 8192
+    raw = synth.make_vdif(10.0, bw_mhz=bw, nchan=nchan)
+    n = 2 * nchan * r
+    payload = o.strip_frames(raw, 8032, 32)
+    nblocks = payload.size * 2 // n
+    assert nblocks == 19
+    d_raw = DeviceBuffer.from_numpy(raw)
+    nfr = raw.size // 8032
+    with ch.Channeliser(pu.lib_cfg(hip_lib, bw, nchan, 10.0), hip_lib) as c:
+        info = c.info
+        pw = DeviceBuffer(nblocks * info.rows_per_block * nchan * 4)
+        c.power_device(d_raw.ptr.value, nfr, 8032, 32, 0, nblocks, pw.ptr.value, pw.nbytes)
+        got = pw.to_numpy(np.float32).reshape(nblocks, -1).astype(np.float64).sum(axis=1)
+    want = np.empty(nblocks)
+    for b in range(nblocks):
+        x = o.unpack_2bit(payload[b * n // 2:(b + 1) * n // 2])
+        e = 0.0
+        for pol in range(2):
+            xs = x[pol]
+            alt = xs[0::2].sum() - xs[1::2].sum()
+            e += (n * (xs * xs).sum() + xs.sum() ** 2 - alt ** 2) / 2.0
+        want[b] = r * e
+    np.testing.assert_allclose(got, want, rtol=2e-6)
+    del pw
+    with ch.Channeliser(pu.lib_cfg(hip_lib, bw, nchan, 10.0, tscr=8), hip_lib) as c:
+        info = c.info
+        rows = nblocks * info.rows_per_block
+        out = DeviceBuffer(rows * info.row_bytes)
+        outs = []
+        for _ in range(2):
+            c.reset()
+            r1 = c.process_device(d_raw.ptr.value, nfr, 8032, 32, 0, nblocks, out.ptr.value, out.nbytes)
+            r1 += c.flush_device(out.ptr.value + r1 * info.row_bytes, out.nbytes - r1 * info.row_bytes)
+            assert r1 == rows
+            outs.append(out.to_numpy(np.uint8))
+        off, sc = c.get_rescale()
+        c.reset()
+        c.set_rescale(off, sc)
+        assert c.process_device(d_raw.ptr.value, nfr, 8032, 32, 0, nblocks, out.ptr.value, out.nbytes) == rows
+        fused = out.to_numpy(np.uint8)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], fused)

@@ -1,17 +1,19 @@
 #!/bin/bash
-# Round artifacts (run on the GPU box): bench line (with its own live PMC traffic passes and the host-inclusive leg), rocprofv3
-# kernel stats of the same workload, per-kernel HBM traffic from separate PMC passes.
-tag=${1:-r02_final}
+# Round artifacts (run on the GPU box): the default bench line (with its own live PMC traffic passes, the host-inclusive legs and
+# the other configurations), rocprofv3 kernel stats of the same workload, per-kernel HBM traffic from separate PMC passes.
+tag=${1:-r03_final}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/$tag
 mkdir -p $out
-timeout -k 10 500 python3 bench.py > $out/bench.json 2> $out/bench.err
+timeout -k 10 700 python3 bench.py > $out/bench.json 2> $out/bench.err
 echo "bench done rc=$?"
-plain="--no-cpu --no-host --no-traffic"
+plain="--no-cpu --no-host --no-traffic --no-configs --no-steady"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py $plain > $out/trace_bench.json 2> $out/trace.err
 echo "trace done rc=$?"
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py $plain --steps 1 --warmup 1 > $out/fetch.log 2>&1
+echo "fetch done rc=$?"
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py $plain --steps 1 --warmup 1 > $out/write.log 2>&1
+echo "write done rc=$?"
 python3 - <<PY
 import csv, glob, collections, json
 res = {}
@@ -32,4 +34,4 @@ if stats:
     shutil.copy(stats[0], "$out/kernel_stats.csv")
     print(open(stats[0]).read()[:2500])
 PY
-cut -c1-2500 $out/bench.json
+cut -c1-1500 $out/bench.json
