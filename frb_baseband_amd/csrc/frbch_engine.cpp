@@ -479,6 +479,11 @@ void launch_kc_fast_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s) {
 }
 bool launch_kc_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   const Plan& pl = h->pl;
+  if (pl.fast_k2_lane == 1) {   // 2C = 64: one lane per block
+    p.nblk = nb;
+    hipLaunchKernelGGL(fast::frbch_kc_lane, dim3((nb + 63) / 64), dim3(64), 0, s, p);
+    return true;
+  }
   switch (pl.fast_k2_log2m) {   // shares the 2C-point tables of the fast K2
     case 1: launch_kc_fast_t<1>(pl, p, nb, s); break;
     case 2: launch_kc_fast_t<2>(pl, p, nb, s); break;
@@ -1659,6 +1664,7 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
     if (pl.fast_k2_lane) {
       snprintf(nm, sizeof nm, "frbch_k2_lane<%d,%d>", pl.fast_k2_lane, h->cfg.pol_mode == 2 ? 2 : (h->cfg.pol_mode >= 4 ? 4 : 0));
       h->kname[KID_K2] = nm;
+      if (pl.fast_k2_lane == 1) h->kname[KID_KC] = "frbch_kc_lane";
     }
 #endif
   }

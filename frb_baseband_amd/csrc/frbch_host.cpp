@@ -390,7 +390,10 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
     // 3.48 ms, one batch of 152 3.40-3.47 ms).
     const uint64_t spill_per_block = pl->n * 8 * (pl->coherent ? 2 : 1);
     maxb = (uint32_t)std::max<uint64_t>(1, ((cfg.pol_mode >= 4 ? 4096ull : 8192ull) << 20) / spill_per_block);   // (one batch of 152 blocks instead of 2 x 76 with four products measured the same, 130.1 vs 130.5 Gsamples/s: the memory is better kept)
-    if (maxb > 256) maxb = 256;
+    // at most 256 blocks per launch, or 2^28 samples of small blocks (32 .. 128 channels: a block is 2^15 .. 2^17 samples and 10 s of
+    // an IF thousands of blocks -- 256 per launch made every kernel launch-bound: 39 launches of ~13 us for 0.5 ms of Kc)
+    const uint64_t cap = std::max<uint64_t>(256, (1ull << 28) / pl->n);
+    if (maxb > cap) maxb = (uint32_t)cap;
   }
   if (maxb > 32768) maxb = 32768;
   while (maxb > 1 && (uint64_t)maxb * pl->block_payload_bytes > (1ull << 31)) maxb /= 2;  // 32-bit launch-relative offsets
