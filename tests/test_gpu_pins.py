@@ -452,3 +452,28 @@ def test_scan_device_lanes_give_the_same_rows(hip_lib, overlap, kw):
     _r, _o, plain, rows = _scan_device(hip_lib, 3, 32.0, 1024, 0.27, overlap=1, **kw)
     _r, _o, lanes, rows2 = _scan_device(hip_lib, 3, 32.0, 1024, 0.27, overlap=overlap, **kw)
     assert rows == rows2 and np.array_equal(plain, lanes)
+
+
+def test_scan_device_coherent_filterbank_rows_equal_the_per_if_rows(hip_lib):
+    """the known-pulsar flags (-D <dm> -F C:D, process_vdif.py:177-180) on several IFs of one GPU: K4 (frbch_k4_fast) writes every
+    IF's rows into its columns of the scan's row buffer -- bit-identical to the IF channelised alone"""
+    kw = dict(dm=26.7, coherent=1, freq=350.0, pol=5, tscr=2)
+    bw, nchan, secs, nif = 32.0, 512, 0.15, 3
+    raws = [synth.make_vdif(secs, bw_mhz=bw, nchan=nchan, if_index=i + 1) for i in range(nif)]
+    bufs = [DeviceBuffer.from_numpy(r) for r in raws]
+    chans = [ch.Channeliser(pu.lib_cfg(hip_lib, -bw if i % 2 else bw, nchan, secs, **kw), hip_lib) for i in range(nif)]
+    info = chans[0].info
+    nfr = raws[0].size // 8032
+    nblocks = (nfr * 8000 - info.block_payload_bytes) // info.block_stride_bytes + 1
+    rows = nblocks * info.rows_per_block
+    out = DeviceBuffer(rows * nif * info.row_bytes)
+    assert multi_if.scan_device(chans, [b.ptr.value for b in bufs], nfr, 8032, 32, 0, nblocks, out.ptr.value, rows) == rows
+    scan = out.to_numpy(np.uint8).reshape(rows, 4, nif * nchan)
+    single = DeviceBuffer(rows * info.row_bytes)
+    for i, c in enumerate(chans):
+        c.reset()
+        r1 = c.process_device(bufs[i].ptr.value, nfr, 8032, 32, 0, nblocks, single.ptr.value, single.nbytes)
+        r1 += c.flush_device(single.ptr.value + r1 * info.row_bytes, single.nbytes - r1 * info.row_bytes)
+        assert r1 == rows
+        assert np.array_equal(single.to_numpy(np.uint8).reshape(rows, 4, nchan), scan[:, :, i * nchan:(i + 1) * nchan])
+        c.close()

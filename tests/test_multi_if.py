@@ -134,6 +134,7 @@ def test_direct_scan_rejects_mixed_geometry(emu_lib, tmp_path):
     dict(nchan=32, freq_res=64, pol=5, interval=0.004, maxb=3),    # four products, interval inside the scan, small batches
     dict(nchan=32, freq_res=64, pol=4, nbit=2, tscr=2, interval=0.0),
     dict(nchan=32, freq_res=64, nbit=16, interval=0.004, const=0, maxb=2),
+    dict(nchan=16, dm=1.0, coherent=1, freq=316.0, pol=4, tscr=2, maxb=2),   # the coherent filterbank (K4 writes the rows) into the scan's columns
     dict(nchan=128, freq_res=512, overlap=160 | (3 << 16) | (1 << 24)),   # two lanes, K2 on the back lane, three batches per IF (emulator: queue order)
     dict(nchan=128, freq_res=512, pol=5, overlap=192 | (2 << 24)),         # two lanes, the digitiser beside the next IF's K1
 ])
@@ -150,7 +151,7 @@ def test_scan_device_rows_are_the_splice_of_the_per_if_rows(emu_lib, kw):
         chans.append(ch.Channeliser(cfg, emu_lib))
     info = chans[0].info
     nfr = raws[0].size // 8032
-    nblocks = (nfr * 8000) // info.block_payload_bytes
+    nblocks = (nfr * 8000 - info.block_payload_bytes) // info.block_stride_bytes + 1     # (overlap-save when coherent)
     rows = nblocks * info.rows_per_block
     # per IF, packed rows
     single = []
@@ -168,7 +169,7 @@ def test_scan_device_rows_are_the_splice_of_the_per_if_rows(emu_lib, kw):
     ptrs = [r.ctypes.data for r in raws]
     got1 = multi_if.scan_device(chans, ptrs, nfr, 8032, 32, 0, half, buf.ctypes.data, rows, flush=False)
     off = got1 * nif_scan * info.row_bytes
-    got2 = multi_if.scan_device(chans, ptrs, nfr, 8032, 32, half * info.block_payload_bytes, nblocks - half,
+    got2 = multi_if.scan_device(chans, ptrs, nfr, 8032, 32, half * info.block_stride_bytes, nblocks - half,
                                 buf.ctypes.data + off, rows - got1, flush=True)
     assert got1 + got2 == rows
     np.testing.assert_array_equal(buf.reshape(want.shape), want)
