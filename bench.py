@@ -135,6 +135,8 @@ WORKLOADS = {
     "cfg4": dict(nif=2, bw=64.0, nchan=4096, pol=2, tscrunch=8, seconds=10.0),                 # configs[3]: one GPU's share (2 IF)
     "cfg5": dict(nif=1, bw=32.0, nchan=2048, pol=2, tscrunch=1, seconds=10.0, freq_res=4096, dm=56.7, coherent=True, freq=1400.0),
     "cfg1": dict(nif=1, bw=16.0, nchan=128, pol=2, tscrunch=1, seconds=10.0),                  # configs[0] shape (parity case)
+    # what the online chain cuts an IF into (submit_job.py:74-105, MinChanPerIF = 32): 32 channels per 32 MHz IF, freq_res 512
+    "online32": dict(nif=1, bw=32.0, nchan=32, pol=2, tscrunch=1, seconds=10.0),
 }
 
 
@@ -660,7 +662,7 @@ def main():
     configs = None
     if world == 1 and not args.no_configs:
         configs = {}
-        for name in ("cfg2", "cfg4", "cfg5"):
+        for name in ("cfg2", "cfg4", "cfg5", "cfg1", "online32"):
             if name == args.workload:
                 continue
             try:
