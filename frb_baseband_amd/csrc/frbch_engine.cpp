@@ -132,6 +132,8 @@ struct frbch_handle {
   uint32_t diag = 0;               // frbch_info::diag
   uint8_t* scan_rows = nullptr;    // frbch_run_scan (first handle of the scan): the row buffer of all its IFs, kept between calls
   size_t scan_rows_bytes = 0;
+  dev_event_t reset_ev{};          // behind the identity rescale a reset queued on the handle's stream
+  bool reset_ev_made = false, reset_pending = false;
   dev_event_t quant_ev{};          // behind a digitiser that ran on the back lane (mode 2)
   bool quant_ev_made = false, quant_busy = false;
   int quant_lane_cus = 0;          // CUs of the lane the digitiser was sent to
@@ -1561,12 +1563,25 @@ int engine_flush(frbch_handle* h, uint8_t* d_out, size_t cap, uint64_t* rows_wri
   return finalize_interval(h, std::min<uint64_t>(h->pow_rows, h->pl.interval_rows), d_out, cap, rows_written, s, ch);
 }
 
+// offset = 0, scale = 1 on the handle's stream.  Not waited for: work that follows on ANOTHER stream is ordered behind an event
+// (join_reset); a reset of the 8 handles of a scan used to cost 8 host round trips with the GPU idle.
 int set_identity_rescale(frbch_handle* h) {
   const Plan& pl = h->pl;
   CHECK_DEV(h, dev_memset32(h->offset, 0u, pl.ncol, h->stream), "clear offset");
   CHECK_DEV(h, dev_memset32(h->scale, 0x3F800000u, pl.ncol, h->stream), "unit scale");     // 1.0f
-  CHECK_DEV(h, dev_sync(h->stream), "sync");   // callers may continue on another stream
+  if (!h->reset_ev_made) {
+    CHECK_DEV(h, dev_event_create_sync(&h->reset_ev), "hipEventCreate");
+    h->reset_ev_made = true;
+  }
+  dev_event_record(h->reset_ev, h->stream);
+  h->reset_pending = true;
   return FRBCH_OK;
+}
+// the device entry points: stream `s` continues behind the handle's pending reset
+void join_reset(frbch_handle* h, dev_stream_t s) {
+  if (!h->reset_pending) return;
+  if (s != h->stream) (void)dev_stream_wait(s, h->reset_ev);
+  h->reset_pending = false;
 }
 
 }  // namespace
@@ -1714,6 +1729,7 @@ extern "C" void frbch_close(frbch_handle* h) {
   if (h->stream) dev_stream_destroy(h->stream);
   if (h->user_ev_made) dev_event_destroy(h->user_ev);
   if (h->quant_ev_made) dev_event_destroy(h->quant_ev);
+  if (h->reset_ev_made) dev_event_destroy(h->reset_ev);
   if (h->region_ev_made) for (auto& e : h->region_ev) dev_event_destroy(e);
   for (auto& e : h->evpool) dev_event_destroy(e);
   delete h;
@@ -1814,6 +1830,7 @@ extern "C" int frbch_process_device(frbch_handle* h, const void* d_frames, size_
   if (stream) {
     if (h->user_stream && h->user_stream != s) { const int rc = settle_user_stream(h); if (rc) return rc; }
   }
+  join_reset(h, s);
   const int rc = engine_feed(h, (const uint8_t*)d_frames, frame_bytes, header_bytes, payload_byte_offset, nblocks,
                              (uint8_t*)d_out, out_cap_bytes, rows_written, s);
   if (stream) mark_user_stream(h, s);
@@ -1828,6 +1845,7 @@ extern "C" int frbch_flush_device(frbch_handle* h, void* d_out, size_t out_cap_b
   if (stream) {
     if (h->user_stream && h->user_stream != s) { const int rc = settle_user_stream(h); if (rc) return rc; }
   }
+  join_reset(h, s);
   const int rc = engine_flush(h, (uint8_t*)d_out, out_cap_bytes, rows_written, s);
   if (stream) mark_user_stream(h, s);
   return rc;
@@ -1859,6 +1877,7 @@ extern "C" int frbch_scan_device(frbch_handle* const* ifs, uint32_t nif, const v
     frbch_handle* h = ifs[i];
     if (h->user_stream && h->user_stream != s) { const int rc = settle_user_stream(h); if (rc) return rc; }
     if (!stream && h != h0) CHECK_DEV(h0, dev_sync(h->stream), "sync");   // (earlier work of this IF on its own stream)
+    join_reset(h, s);
   }
   // one chain over all IFs: the front stages of IF i + 1 overlap the back stages (and the flush) of IF i
   Lanes* ln = overlap_usable(h0) ? get_lanes(h0->device, overlap_front_cus(h0)) : nullptr;
@@ -1911,6 +1930,7 @@ extern "C" int frbch_power_device(frbch_handle* h, const void* d_frames, size_t 
   if (stream) {
     if (h->user_stream && h->user_stream != s) { const int rc = settle_user_stream(h); if (rc) return rc; }
   }
+  join_reset(h, s);
   for (uint64_t b0 = 0; b0 < nblocks; b0 += pl.maxb) {
     const uint32_t nb = (uint32_t)std::min<uint64_t>(pl.maxb, nblocks - b0);
     KParams p = base_params(h);
