@@ -169,8 +169,8 @@ struct DeviceGuard {
 };
 
 // kernel-selection switches a product build accepts (include/frbch.h); everything else is an experiment
-constexpr uint32_t kProductFlags = 1u | 2u | 4u | 8u | 16u | 32u | 64u | 128u | (1u << 20) | (1u << 21) | (1u << 22) | (1u << 23) | (1u << 24);
-constexpr uint32_t kFlagNoPipeline = 1u << 22, kFlagNoK0 = 1u << 23;
+constexpr uint32_t kProductFlags = 1u | 2u | 4u | 8u | 16u | 32u | 64u | 128u | (1u << 20) | (1u << 21) | (1u << 22) | (1u << 23) | (1u << 24) | (1u << 25);
+constexpr uint32_t kFlagNoPipeline = 1u << 22, kFlagNoK0 = 1u << 23, kFlagGenericQuant = 1u << 25;
 #ifdef FRBCH_EXPERIMENTS
 constexpr uint32_t kAcceptedFlags = kProductFlags | 0x000FFF00u;
 #else
@@ -1099,6 +1099,32 @@ int run_quantise(frbch_handle* h, uint64_t rows, uint8_t* dst, dev_stream_t s, i
   while ((1ull << qp.log2_ncol) < pl.ncol) ++qp.log2_ncol;
   qp.pitch = h->out_pitch ? h->out_pitch : (uint64_t)pl.c;
   ProfScope ps(h, s, KID_QUANT, (double)rows * (pl.ncol * 4.0 + pl.row_bytes));
+#ifndef FRBCH_NO_FAST
+  {
+    // 8-bit codes of power-of-two rows: the lean stream (frbch_quantise_fast): every thread one column group, threads = row
+    // phases x column groups.  The loads a thread has in flight are `rphases` rows apart, and the HBM address hash does not like
+    // every distance: 3 workgroups per CU (four products at 1024 channels: 192 phases, the loads 3 MiB apart) measured 9.1 ms per
+    // 8 IFs of config 3, 1 / 2 / 4 / 6 / 8 / 16 per CU 9.7 / 10.6 / 11.1 / 9.5 / 11.1 / 10.4, odd phase counts 63 / 95 / 127 / 191 /
+    // 193 / 255 / 383 / 511: 10.1 / 9.5 / 10.5 / 9.4 / 10.1 / 11.2 / 10.1 / 11.8 (generic kernel: 9.9)
+    const uint64_t cg = pl.ncol / 4;
+    const bool pow2 = (pl.ncol & (pl.ncol - 1)) == 0 && (pl.c & (pl.c - 1)) == 0;
+    uint64_t rp = (uint64_t)(ncu > 0 ? ncu : 256) * (uint64_t)(wgs_env > 0 ? wgs_env : 3) * 256 / std::max<uint64_t>(1, cg);
+#ifdef FRBCH_EXPERIMENTS
+    static const int rp_env = getenv("FRBCH_QUANT_RP") ? atoi(getenv("FRBCH_QUANT_RP")) : 0;
+    if (rp_env > 0) rp = (uint64_t)rp_env;
+#endif
+    const uint64_t wgs = rp * cg / 256;
+    if (!(h->cfg.flags & kFlagGenericQuant) && qp.nbit == 8 && qp.digi_max == 255.0f && pow2 && pl.c >= 4 && cg >= 64 && wgs > 0 &&
+        (wgs * 256) == rp * cg && qp.pitch % 4 == 0 && rp * (uint64_t)pl.nif * qp.pitch < (1ull << 31) && rp * pl.ncol * 4 < (1ull << 31)) {
+      qp.grid_x = (uint32_t)wgs;
+      qp.rphases = (uint32_t)(wgs * 256 / cg);
+      h->kname[KID_QUANT] = "frbch_quantise_fast<8>";
+      hipLaunchKernelGGL(fast::frbch_quantise_fast<8>, dim3(qp.grid_x), dim3(256), 0, s, qp);
+      CHECK_DEV(h, dev_check_launch(), "launch quantise");
+      return FRBCH_OK;
+    }
+  }
+#endif
   DEV_LAUNCH(frbch_quantise, qp.grid_x, 1, 256, 0, s, qp);
   CHECK_DEV(h, dev_check_launch(), "launch quantise");
   return FRBCH_OK;

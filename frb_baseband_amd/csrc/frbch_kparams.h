@@ -121,6 +121,7 @@ struct QuantParams {
   int log2_c;
   int log2_ncol;
   uint64_t pitch;           // output values between consecutive (row, product) lines (KParams::out_pitch)
+  uint32_t rphases;         // frbch_quantise_fast: row phases = grid_x * 256 / (ncol / 4); a thread takes rows phase + i * rphases
 };
 #define QUANT_GRID_X(p) ((p).grid_x)
 

@@ -67,7 +67,9 @@ typedef struct frbch_config {
                                 * 1<<21 slab layout of the spill where the tile-major one would be used, 1<<22 whole-file paths
                                 * without reader / writer threads, 1<<23 K1 gathers from the frames (no corner-turned copy),
                                 * 1<<24 frbch_k1_split (R = 2048: bin-parity halves, 16 independent waves per CU; measured 14 %
-                                * slower than the default wave K1, kept as a parity-tested alternative).
+                                * slower than the default wave K1, kept as a parity-tested alternative),
+                                * 1<<25 the generic digitiser (frbch_quantise) for a buffered rescale interval where the lean
+                                * 8-bit stream (frbch_quantise_fast) would run.
                                 * Any other bit makes frbch_open fail with FRBCH_E_ARG: bits 8..19 (timing-only ablations that
                                 * produce WRONG output) and the environment knobs of the profiling notes exist only in
                                 * libraries built with -DFRBCH_EXPERIMENTS (make EXPERIMENTS=1), never in the product build. */

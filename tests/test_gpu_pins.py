@@ -53,6 +53,9 @@ def _unpack_codes(buf, nbit, shape):
     (16.0, 128, 0.05, 4, 2, 8, 0),
     (64.0, 4096, 1.1, 2, 8, 8, 0),             # config 4 kernels (M = 32 barrier kernels), -t 8
     (32.0, 1024, 0.27, 2, 8, 1, 3),            # generic kernels
+    (32.0, 1024, 0.2, 2, 8, 16, 0),            # frbch_quantise_fast: fewer rows (384) than row phases: only its checked tail runs
+    (32.0, 1024, 0.6, 5, 8, 1, 0),             # ... 9 blocks: an even number of pipelined trips + left-over steps
+    (-32.0, 1024, 0.27, 4, 8, 1, 1 << 25),     # the generic digitiser where the lean one would run
 ])
 def test_rescale_and_digitiser_are_bit_exact_on_the_hip_floats(hip_lib, bw, nchan, secs, pol, nbit, tscr, flags):
     raw = synth.make_vdif(secs, bw_mhz=abs(bw), nchan=nchan)

@@ -45,10 +45,10 @@ def test_hdr_values_that_do_not_fit_are_argument_errors(tmp_path, hip_lib):
 
 
 def test_unknown_flag_bits_are_rejected(emu_lib):
-    for bad in (1 << 8, 1 << 12, 1 << 19, 1 << 25, 1 << 31):
+    for bad in (1 << 8, 1 << 12, 1 << 19, 1 << 26, 1 << 31):
         with pytest.raises(ch.InputError, match="unknown bit"):
             ch.Channeliser(ch.new_config(emu_lib, flags=bad), emu_lib)
-    ch.Channeliser(ch.new_config(emu_lib, flags=(1 << 20) | (1 << 22)), emu_lib).close()
+    ch.Channeliser(ch.new_config(emu_lib, flags=(1 << 20) | (1 << 22) | (1 << 25)), emu_lib).close()
 
 
 def test_product_library_is_not_an_experiments_build(hip_lib):
