@@ -435,6 +435,39 @@ def roofline_of(timing, steps):
     return name, rec, ach
 
 
+def kernels_overlap(timing, steps, dt):
+    """True when the per-kernel HIP-event times add up to visibly more than the step: kernels shared the chip"""
+    return sum(v["total_ms"] for v in timing.values()) > 1.02 * dt * 1e3
+
+
+def concurrency_note(timing, steps, dt):
+    if not kernels_overlap(timing, steps, dt):
+        return "kernels run one after the other on the whole chip"
+    return ("in a scan the first-interval digitiser of IF i (frbch_quantise_fast, on CUs it holds by an LDS reservation, own plain "
+            "stream) runs beside the K1 of IF i + 1 (frbch_config.overlap automatic = mode 3, DESIGN.md section 4b): a kernel's launch "
+            "duration is its time on ITS share of the chip and of HBM, and the sum over kernels exceeds ms_per_step; `overlapped_pair` "
+            "prices the two together")
+
+
+def overlapped_pair(timing, steps, dt):
+    """K1 and the digitiser while they share the chip: their algorithmic bytes over the longer of the two totals (the first K1 and
+    the last digitiser of a step run alone: approximate by that much)"""
+    if not kernels_overlap(timing, steps, dt):
+        return None
+    k1 = [k for k in timing if k.startswith("frbch_k1_")]
+    q = [k for k in timing if k.startswith("frbch_quantise")]
+    if not k1 or not q:
+        return None
+    a, b = timing[k1[0]], timing[q[0]]
+    ms = max(a["total_ms"], b["total_ms"])
+    if ms <= 0:
+        return None
+    gbs = (a["algorithmic_bytes"] + b["algorithmic_bytes"]) / (ms * 1e-3) / 1e9
+    return {"kernels": [k1[0], q[0]], "ms_per_step": round(ms / steps, 4),
+            "algorithmic_bytes_per_step": (a["algorithmic_bytes"] + b["algorithmic_bytes"]) / steps,
+            "achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+
+
 def host_inclusive(args, torch, dist, wl, rank, world):
     """What the reference's calls do end to end: VDIF files -> .fil, PCIe both ways and the host threads included; files on
     tmpfs (disk excluded).  One IF through frbch_run_file (process_vdif.py:191 `digifil ... -o out hdr`), and -- when the GPU
@@ -706,10 +739,12 @@ def main():
                 "launches_per_step": rec["launches"] / args.steps,
                 "algorithmic_bytes_per_launch": rec["algorithmic_bytes"] / max(1, rec["launches"]),
                 "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in timing.items() if v["launches"]},
-                "concurrency": ("kernels run one after the other on the whole chip (frbch_config.overlap automatic = off: two CU-masked "
-                                "lanes were measured slower, profiles/r03_overlap_sweep_*.txt)") if (args.overlap & 0xFFFF) in (0, 1) else
-                               ("front stages (K0, K1, Kc) and back stages run on two CU-masked streams and overlap: a kernel's launch "
-                                "duration is its time on ITS share of the CUs, the sum over kernels exceeds ms_per_step"),
+                "per_kernel": {k: {"ms_per_step": round(v["total_ms"] / args.steps, 4),
+                                   "achieved": round(v["algorithmic_bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1),
+                                   "frac": round(v["algorithmic_bytes"] / (v["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                               for k, v in timing.items() if v["launches"] and v["total_ms"] > 0},
+                "concurrency": concurrency_note(timing, args.steps, dt),
+                "overlapped_pair": overlapped_pair(timing, args.steps, dt),
                 "valu": valu,
                 "whole_path": {"algorithmic_bytes_per_sample": round(bps, 3),
                                "achieved": round(value / world * 1e6 * bps / 1e9, 1),

@@ -123,6 +123,7 @@ struct frbch_handle {
   // two-lane pipeline: spill regions in flight, ordering events
   uint8_t* stg_cur = nullptr;      // staged payload of the launch in progress (stg + region offset)
   int lane_cus = 0;                // compute units of the stream the next K1 goes to (0 = all of them)
+  int lane_ncu = 0;                // compute units of the device (frbch_open)
   dev_event_t region_ev[8];        // recorded behind the last back stage that read spill region r
   bool region_busy[8] = {false, false, false, false, false, false, false, false};
   bool region_ev_made = false;
@@ -1064,6 +1065,27 @@ int run_stats(frbch_handle* h, uint64_t rows, dev_stream_t s) {
   return FRBCH_OK;
 }
 
+// Geometry of the lean 8-bit digitiser (frbch_quantise_fast) on `ncu` CUs (0 = the whole chip; negative: |ncu| CUs held by one
+// 512-thread workgroup each, see run_quantise): workgroups, threads per workgroup and row phases; false = the generic kernel runs
+bool quant_fast_geometry(const frbch_handle* h, int ncu, int wgs_per_cu, uint64_t rp_force, uint64_t* wgs_out, uint64_t* nthr_out, uint64_t* rp_out) {
+  const Plan& pl = h->pl;
+  if ((h->cfg.flags & kFlagGenericQuant) || h->cfg.nbit_out != 8 || pl.digi_max != 255.0f) return false;
+  const uint64_t cg = pl.ncol / 4;
+  const bool pow2 = (pl.ncol & (pl.ncol - 1)) == 0 && (pl.c & (pl.c - 1)) == 0;
+  if (!pow2 || pl.c < 4 || cg < 64) return false;
+  const bool excl = ncu < 0;
+  const uint64_t nthr = excl ? 512 : 256;
+  uint64_t rp = excl ? (uint64_t)(-ncu) * nthr / cg : (uint64_t)(ncu > 0 ? ncu : 256) * (uint64_t)(wgs_per_cu > 0 ? wgs_per_cu : 3) * 256 / cg;
+  if (rp_force) rp = rp_force;
+  const uint64_t wgs = rp * cg / nthr;
+  const uint64_t pitch = h->out_pitch ? h->out_pitch : (uint64_t)pl.c;
+  if (!wgs || wgs * nthr != rp * cg || pitch % 4 || rp * (uint64_t)pl.nif * pitch >= (1ull << 31) || rp * pl.ncol * 4 >= (1ull << 31)) return false;
+  *wgs_out = wgs;
+  *nthr_out = nthr;
+  *rp_out = rp;
+  return true;
+}
+
 int run_quantise(frbch_handle* h, uint64_t rows, uint8_t* dst, dev_stream_t s, int ncu = 0) {
   const Plan& pl = h->pl;
   QuantParams qp;
@@ -1091,7 +1113,7 @@ int run_quantise(frbch_handle* h, uint64_t rows, uint8_t* dst, dev_stream_t s, i
 #else
   const int wgs_env = 0;
 #endif
-  const uint64_t gx = std::min<uint64_t>((total + 256 * 4 - 1) / (256 * 4), (uint64_t)(ncu > 0 ? ncu : 256) * (uint64_t)(wgs_env > 0 ? wgs_env : 32));
+  const uint64_t gx = std::min<uint64_t>((total + 256 * 4 - 1) / (256 * 4), (uint64_t)(ncu != 0 ? std::abs(ncu) : 256) * (uint64_t)(wgs_env > 0 ? wgs_env : 32));
   qp.grid_x = (uint32_t)std::max<uint64_t>(1, gx);
   qp.log2_c = 0;
   while ((1 << qp.log2_c) < pl.c) ++qp.log2_c;
@@ -1106,20 +1128,28 @@ int run_quantise(frbch_handle* h, uint64_t rows, uint8_t* dst, dev_stream_t s, i
     // every distance: 3 workgroups per CU (four products at 1024 channels: 192 phases, the loads 3 MiB apart) measured 9.1 ms per
     // 8 IFs of config 3, 1 / 2 / 4 / 6 / 8 / 16 per CU 9.7 / 10.6 / 11.1 / 9.5 / 11.1 / 10.4, odd phase counts 63 / 95 / 127 / 191 /
     // 193 / 255 / 383 / 511: 10.1 / 9.5 / 10.5 / 9.4 / 10.1 / 11.2 / 10.1 / 11.8 (generic kernel: 9.9)
-    const uint64_t cg = pl.ncol / 4;
-    const bool pow2 = (pl.ncol & (pl.ncol - 1)) == 0 && (pl.c & (pl.c - 1)) == 0;
-    uint64_t rp = (uint64_t)(ncu > 0 ? ncu : 256) * (uint64_t)(wgs_env > 0 ? wgs_env : 3) * 256 / std::max<uint64_t>(1, cg);
+    // ncu < 0: |ncu| workgroups of 512 threads, each reserving more than half the LDS: one per CU, and no wave K1 workgroup (148 KB)
+    // beside it -- the digitiser holds |ncu| CUs to itself on a plain stream while the next IF's K1 runs on the others.  (16 loads
+    // in flight per thread or 1024 threads per workgroup: the same time; the two kernels together move 5.2 TB/s.)
+    const bool excl = ncu < 0;
 #ifdef FRBCH_EXPERIMENTS
     static const int rp_env = getenv("FRBCH_QUANT_RP") ? atoi(getenv("FRBCH_QUANT_RP")) : 0;
-    if (rp_env > 0) rp = (uint64_t)rp_env;
+#else
+    const int rp_env = 0;
 #endif
-    const uint64_t wgs = rp * cg / 256;
-    if (!(h->cfg.flags & kFlagGenericQuant) && qp.nbit == 8 && qp.digi_max == 255.0f && pow2 && pl.c >= 4 && cg >= 64 && wgs > 0 &&
-        (wgs * 256) == rp * cg && qp.pitch % 4 == 0 && rp * (uint64_t)pl.nif * qp.pitch < (1ull << 31) && rp * pl.ncol * 4 < (1ull << 31)) {
+    uint64_t wgs = 0, nthr = 0, rp = 0;
+    if (quant_fast_geometry(h, ncu, wgs_env, excl ? 0 : (uint64_t)rp_env, &wgs, &nthr, &rp)) {
       qp.grid_x = (uint32_t)wgs;
-      qp.rphases = (uint32_t)(wgs * 256 / cg);
+      qp.rphases = (uint32_t)rp;
       h->kname[KID_QUANT] = "frbch_quantise_fast<8>";
-      hipLaunchKernelGGL(fast::frbch_quantise_fast<8>, dim3(qp.grid_x), dim3(256), 0, s, qp);
+      if (excl) {
+        constexpr size_t kHold = 84 * 1024;
+        static const int allowed = dev_allow_lds(fast::frbch_quantise_fast<8, 512>, kHold);
+        CHECK_DEV(h, allowed, "LDS size digitiser");
+        hipLaunchKernelGGL((fast::frbch_quantise_fast<8, 512>), dim3(qp.grid_x), dim3(512), kHold, s, qp);
+      } else {
+        hipLaunchKernelGGL((fast::frbch_quantise_fast<8, 256>), dim3(qp.grid_x), dim3(256), 0, s, qp);
+      }
       CHECK_DEV(h, dev_check_launch(), "launch quantise");
       return FRBCH_OK;
     }
@@ -1150,6 +1180,7 @@ uint64_t out_extent(const frbch_handle* h, uint64_t rows) {
 // Close the rescale interval that sits at the front of powbuf: statistics over `stat_rows` rows,
 // then digitise `emit_rows` rows into dst and keep the rest for the next interval.
 struct Chain;
+int chain_quant_lane_cus(const Chain* c);
 dev_stream_t chain_quant_stream(Chain* c, dev_stream_t s, int* ncu);
 void chain_quant_done(Chain* c, dev_stream_t sq);
 int finalize_interval(frbch_handle* h, uint64_t stat_rows, uint8_t* d_out, size_t cap, uint64_t* rows_written,
@@ -1157,7 +1188,13 @@ int finalize_interval(frbch_handle* h, uint64_t stat_rows, uint8_t* d_out, size_
   const Plan& pl = h->pl;
   int rc = run_stats(h, stat_rows, s0);
   if (rc) return rc;
-  const dev_stream_t s = chain_quant_stream(ch, s0, &h->quant_lane_cus);   // (the back lane when the digitiser can run beside the next K1)
+  // the back lane when the digitiser can run beside the next K1 (on CUs it holds by an LDS reservation: only the lean kernel does that)
+  dev_stream_t s = s0;
+  {
+    const int lane = chain_quant_lane_cus(ch);
+    uint64_t a_ = 0, b_ = 0, c_ = 0;
+    if (lane > 0 || (lane < 0 && quant_fast_geometry(h, lane, 0, 0, &a_, &b_, &c_))) s = chain_quant_stream(ch, s0, &h->quant_lane_cus);
+  }
   h->have_scale = true;
   if (h->cfg.rescale_constant) h->scale_frozen = true;
   const uint64_t emit_rows = h->scale_frozen ? h->pow_rows : stat_rows;
@@ -1206,13 +1243,23 @@ struct Lanes {
 std::mutex g_lanes_mutex;
 std::vector<std::pair<std::pair<int, int>, Lanes*>> g_lanes;   // (device, front CUs) -> lanes; live until the process ends
 
-Lanes* get_lanes(int device, int ncu_front) {
+Lanes* get_lanes(int device, int ncu_front, bool plain = false) {
   std::lock_guard<std::mutex> lk(g_lanes_mutex);
+  const int key = plain ? -ncu_front : ncu_front;
   for (auto& e : g_lanes)
-    if (e.first.first == device && e.first.second == ncu_front) return e.second->ok ? e.second : nullptr;
+    if (e.first.first == device && e.first.second == key) return e.second->ok ? e.second : nullptr;
   Lanes* ln = new Lanes();
-  g_lanes.push_back({{device, ncu_front}, ln});
+  g_lanes.push_back({{device, key}, ln});
   ln->ncu = dev_cu_count(device);
+  if (plain && ln->ncu > 0) {
+    // mode 3: plain streams (no CU masks: a masked queue costs every launch of the process 50 - 100 us while it is active,
+    // profiles/NOTES.md); the digitiser claims its CUs by its LDS reservation, ncu_f is what is left for the K1 beside it
+    if (ncu_front < 8 || ncu_front > ln->ncu - 8) return nullptr;
+    if (dev_stream_create(&ln->f) != 0 || dev_stream_create(&ln->b) != 0 || dev_stream_create(&ln->b2) != 0) return nullptr;
+    ln->ncu_f = ncu_front;
+    ln->ok = true;
+    return ln;
+  }
   if (ncu_front >= ln->ncu && ln->ncu > 0) {
     // no partition: plain streams.  Kernels of the two lanes share every CU as far as its registers, LDS and wave slots go
     // (the digitiser's 4-wave workgroups fit beside the wave K1's eight 216-register waves: one per CU)
@@ -1260,6 +1307,7 @@ struct Chain {
   dev_stream_t s_front = 0, s_back = 0;   // streams of the last front / back stage queued
   bool f_rooted = false, b_rooted = false, b2_rooted = false;
   bool q_pending = false, have_q = false; // mode 2: a digitiser runs on the back lane (the next front stage goes beside it)
+  bool front_beside_q = false;            // mode 3: the front stage being queued shares the chip with a digitiser
 };
 
 void chain_begin(Chain* c, frbch_handle* owner, dev_stream_t user, Lanes* ln, uint32_t stages_total, bool k0_back, int mode) {
@@ -1278,6 +1326,11 @@ void chain_begin(Chain* c, frbch_handle* owner, dev_stream_t user, Lanes* ln, ui
 // stream of the next front stage: the first one has the chip to itself (nothing to overlap with yet)
 dev_stream_t chain_front_stream(Chain* c) {
   if (!c->ln || c->fronts == 0) return c->user;
+  if (c->mode == 3) {   // the caller's stream throughout; only the K1 grid changes while a digitiser holds part of the chip
+    c->front_beside_q = c->q_pending;
+    c->q_pending = false;
+    return c->user;
+  }
   if (c->mode == 2) {
     if (!c->q_pending) return c->user;
     c->q_pending = false;
@@ -1314,7 +1367,7 @@ void chain_front_done(Chain* c, dev_stream_t sf) {
 // stream of the next back stage (ordered behind its front stage and the previous back stage)
 dev_stream_t chain_back_stream(Chain* c) {
   if (!c->ln) return c->user;
-  if (c->mode == 2) {
+  if (c->mode >= 2) {
     if (c->s_front != c->user) (void)dev_stream_wait(c->user, c->ev_front);
     return c->user;
   }
@@ -1339,10 +1392,15 @@ void chain_back_done(Chain* c, dev_stream_t sb) {
 // everything the chain queued is ordered in front of what follows on the caller's stream
 // mode 2: the stream the digitiser of a completed interval goes to -- the back lane while another front stage is still to
 // come (it runs beside that stage's K1), else the stream `s` of the statistics in front of it
+int chain_quant_lane_cus(const Chain* c) {   // CUs the digitiser would get on the back lane (negative: held by its LDS reservation); 0 = no lane
+  if (!c || !c->ln || c->mode < 2 || c->fronts >= c->stages_total) return 0;
+  const int n = c->ln->ncu_f >= c->ln->ncu ? c->ln->ncu : c->ln->ncu - c->ln->ncu_f;
+  return c->mode == 3 ? -n : n;
+}
 dev_stream_t chain_quant_stream(Chain* c, dev_stream_t s, int* ncu) {
-  if (!c || !c->ln || c->mode != 2 || c->fronts >= c->stages_total) return s;
+  if (!chain_quant_lane_cus(c)) return s;
   const dev_stream_t sq = c->ln->b;
-  *ncu = c->ln->ncu_f >= c->ln->ncu ? c->ln->ncu : c->ln->ncu - c->ln->ncu_f;
+  *ncu = chain_quant_lane_cus(c);
   if (!c->b_rooted) {
     (void)dev_stream_wait(sq, c->ev_entry);
     c->b_rooted = true;
@@ -1353,7 +1411,7 @@ dev_stream_t chain_quant_stream(Chain* c, dev_stream_t s, int* ncu) {
   return sq;
 }
 void chain_quant_done(Chain* c, dev_stream_t sq) {
-  if (!c || !c->ln || c->mode != 2 || sq != c->ln->b) return;
+  if (!c || !c->ln || c->mode < 2 || sq != c->ln->b) return;
   c->ev_q = pool_event(c->owner);
   dev_event_record(c->ev_q, sq);
   c->q_pending = true;
@@ -1383,10 +1441,15 @@ int overlap_front_cus(const frbch_handle* h) {
 #endif
   if (v == 1) return 0;                       // overlap off
   if (v) return (int)(v / 8 * 8);
-  // automatic = no overlap.  Measured (profiles/r03_overlap_sweep_*.txt): K1 AND K2 both scale with
-  // their share of the CUs (K2 on 96 CUs takes 2.4x its whole-chip time: it is bound by its waves' chains, not by HBM, as
-  // soon as it has fewer CUs), so splitting the chip between them only adds the ramps of more launches (cfg 2: 3.33 -> 3.7 -
-  // 5.1 ms per step); the digitiser on a 64-CU lane beside the next IF's K1 loses to the K2 that follows on all CUs.
+  // automatic.  K1 against K2 (mode 1): never -- both scale with their share of the CUs (K2 on 96 CUs takes 2.4x its
+  // whole-chip time), splitting the chip between them only adds launches (profiles/r03_overlap_sweep_*.txt).
+  // The digitiser of a completed interval beside the next IF's K1 (mode 3, a scan): yes when it is a stream of four products
+  // -- 6.4 GB per IF, HBM-bound on the whole chip with most CUs idle, while K1 is bound by its waves and leaves HBM half idle.
+  // 80 of 256 CUs for the digitiser make both take ~2.3 ms (1.55 + 1.14 one after the other): 39.5 -> 36.4 ms per 8-IF step of
+  // config 3, the two together moving 5.2 TB/s.  One product (1.6 GB): what it hides is what K1 loses on fewer CUs: off.
+  const Plan& pl = h->pl;
+  if (pl.nif == 4 && h->cfg.nbit_out == 8 && pl.fast_k1_log2m == 3 && pl.fast_k1_wave && !pl.fast_k1_split && h->lane_ncu >= 64)
+    return h->lane_ncu * 11 / 16 / 8 * 8;
   return 0;
 }
 int overlap_mode(const frbch_handle* h) {
@@ -1395,7 +1458,7 @@ int overlap_mode(const frbch_handle* h) {
   static const int env = getenv("FRBCH_OVERLAP_MODE") ? atoi(getenv("FRBCH_OVERLAP_MODE")) : 0;
   if (env > 0) return env;
 #endif
-  return m ? (int)m : 2;
+  return m ? (int)m : 3;
 }
 bool overlap_usable(const frbch_handle* h) {
   const Plan& pl = h->pl;
@@ -1477,7 +1540,7 @@ int engine_feed_run(frbch_handle* h, const uint8_t* d_frames, uint32_t frame_byt
   Chain* ch = outer;
   const bool may_overlap = !d_fbad && overlap_usable(h);
   Lanes* ln = nullptr;
-  if (!ch && may_overlap) ln = get_lanes(h->device, overlap_front_cus(h));
+  if (!ch && may_overlap) ln = get_lanes(h->device, overlap_front_cus(h), overlap_mode(h) == 3);
   if (!ch && overlap_mode(h) != 1) ln = nullptr;     // (mode 2 only overlaps across the IFs of a scan: the caller's chain)
   const bool overlap = ch ? (ch->ln != nullptr && ch->mode == 1) : (ln != nullptr);   // batches cut for two regions in flight
   uint64_t nbatch = 0, per = 0;
@@ -1516,7 +1579,7 @@ int engine_feed_run(frbch_handle* h, const uint8_t* d_frames, uint32_t frame_byt
     h->region_busy[reg] = false;
     const dev_stream_t sk = chain_k0_stream(ch, sf);
     if (sk != sf && region_wait) (void)dev_stream_wait(sk, h->region_ev[reg]);
-    h->lane_cus = (ch->ln && sf == ch->ln->f) ? ch->ln->ncu_f : 0;
+    h->lane_cus = (ch->ln && (sf == ch->ln->f || (ch->mode == 3 && ch->front_beside_q))) ? ch->ln->ncu_f : 0;
     rc = launch_front(h, p, nb, sf, sk);
     h->lane_cus = 0;
     if (rc) break;
@@ -1659,6 +1722,7 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
   DeviceGuard dg(h->device);
   char arch[128] = "";
   if (!dev_arch_ok(h->device, arch, sizeof arch, &h->lds_limit)) return fail(h, FRBCH_E_DEVICE, "cannot query device");
+  h->lane_ncu = dev_cu_count(h->device);
   const std::string why = make_plan(h->cfg, &h->pl, h->lds_limit);
   if (!why.empty()) return fail(h, FRBCH_E_ARG, why);
   const Plan& pl = h->pl;
@@ -1906,7 +1970,7 @@ extern "C" int frbch_scan_device(frbch_handle* const* ifs, uint32_t nif, const v
     join_reset(h, s);
   }
   // one chain over all IFs: the front stages of IF i + 1 overlap the back stages (and the flush) of IF i
-  Lanes* ln = overlap_usable(h0) ? get_lanes(h0->device, overlap_front_cus(h0)) : nullptr;
+  Lanes* ln = overlap_usable(h0) ? get_lanes(h0->device, overlap_front_cus(h0), overlap_mode(h0) == 3) : nullptr;
   uint64_t stages = 0;
   for (uint32_t i = 0; i < nif; ++i) stages += feed_stage_count(ifs[i], nblocks, ln != nullptr && overlap_mode(h0) == 1);
   Chain ch;

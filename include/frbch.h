@@ -80,13 +80,16 @@ typedef struct frbch_config {
   char datafile[512];          /* .hdr DATAFILE   (:129)                                      */
   uint32_t input_bits;         /* bits per sample of the VDIF: 2, or 1 (mode VDIF_8000-1024-16-1, spif2file.sh:58-61);
                                 * 0 = take it from the first frame header (host paths) / 2 (device paths)            */
-  uint32_t overlap;            /* 0 in production (automatic).  Two lanes of the device work on streams with complementary CU
-                                * masks: bits 0..15 compute units of the front lane (K0, K1, Kc; multiple
-                                * of 8; 1 = no overlap: every kernel on the whole chip, one after the other); bits 24..25 what
-                                * runs on the back lane: 2 (automatic choice) = only the digitiser of a completed rescale
-                                * interval, beside the K1 of the next IF of a scan; 1 = K2, statistics and digitiser, beside the
-                                * K1 of the next batch (measured slower: both kernels scale with their share of the CUs), with
-                                * bits 16..23 = batches a call is cut into.  Every setting produces the same output.            */
+  uint32_t overlap;            /* 0 in production (automatic).  Two kernels of a scan share the device.
+                                * Bits 0..15: compute units left to the front kernels (K0, K1, Kc; multiple of 8; 1 = no overlap:
+                                * every kernel on the whole chip, one after the other).  Bits 24..25, what runs beside them:
+                                * 3 (automatic choice) = the digitiser of a completed rescale interval beside the K1 of the next IF
+                                * of a scan, on plain streams -- it holds the other CUs by an LDS reservation (automatic: four
+                                * products at 8 bits, 11/16 of the CUs for K1; else off); 2 = the same on streams with complementary
+                                * CU masks (measured slower: a masked queue delays every launch); 1 = K2, statistics and digitiser
+                                * on a masked back lane beside the K1 of the next batch (measured slower: both kernels scale with
+                                * their share of the CUs), with bits 16..23 = batches a call is cut into.  Every setting produces
+                                * the same output.                                                                              */
   float levels[4];             /* 2-bit level table, state 0..3 -> voltage (process_vdif.py:157 passes the bare `-2`: DSPSR's
                                 * static table); all four 0 = the default -3.3359, -1, +1, +3.3359.  A run-time table in
                                 * every kernel, so another level scheme is a data change.                                  */

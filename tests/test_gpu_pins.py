@@ -448,6 +448,8 @@ def test_scan_device_config3_as_stated_against_the_oracle(hip_lib):
     (128 | (3 << 16) | (1 << 24), dict(pol=5, interval=0.1, maxb=2)),          # ... four products, the interval ends inside the scan
     (192 | (2 << 24), dict(pol=5)),                                            # the digitiser beside the next IF's K1
     (192 | (2 << 24), dict(pol=2, interval=0.1, const=0, nbit=16, maxb=2)),    # ... an interval per 0.1 s (the power buffer is re-used)
+    (192 | (3 << 24), dict(pol=5)),                                            # ... on plain streams, its CUs held by an LDS reservation
+    (160 | (3 << 24), dict(pol=2, interval=0.1, const=0, maxb=2)),
 ])
 def test_scan_device_lanes_give_the_same_rows(hip_lib, overlap, kw):
     """the CU-masked lanes change WHERE and WHEN kernels run, never what they write: rows identical to the run without
