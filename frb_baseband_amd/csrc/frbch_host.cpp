@@ -383,7 +383,7 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
 
   uint32_t maxb = cfg.max_blocks_per_launch;
   if (!maxb) {
-    // big batches amortise launches and let the persistent kernels run many iterations: up to 8 GiB of spill (the power
+    // big batches amortise launches and let the persistent kernels run many iterations: up to 8 GiB of spill, 5 GiB with four products (the power
     // buffer, the staging areas and a scan's row buffer grow with the batch and with the products; the eight handles of a
     // config-3 scan take ~12 GB each: the card has 288).  Callers split their blocks
     // into EQUAL batches (measured, 152-block scan: 64 + 64 + 24 blocks 3.60 ms per step, 3 x 51 3.61 ms, 76 + 76
@@ -391,7 +391,9 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
     const uint64_t spill_per_block = pl->n * 8 * (pl->coherent ? 2 : 1);
     // (four products: one batch of 152 blocks instead of 2 x 76 measured the same on its own, 130.1 vs 130.5 Gsamples/s, but the
     // digitiser of IF i beside the K1 of IF i + 1 wants ONE long K1 launch: 37.25 -> 36.4 ms per 8-IF step)
-    maxb = (uint32_t)std::max<uint64_t>(1, (8192ull << 20) / spill_per_block);
+    // (the spill is allocated for maxb blocks: 5 GiB with four products = 160 blocks of 2^22 samples, the 152 of a 10-s IF in one piece;
+    // 8 GiB would double what the eight handles of a config-3 scan hold for nothing)
+    maxb = (uint32_t)std::max<uint64_t>(1, ((cfg.pol_mode >= 4 ? 5120ull : 8192ull) << 20) / spill_per_block);
     // at most 256 blocks per launch, or 2^28 samples of small blocks (32 .. 128 channels: a block is 2^15 .. 2^17 samples and 10 s of
     // an IF thousands of blocks -- 256 per launch made every kernel launch-bound: 39 launches of ~13 us for 0.5 ms of Kc)
     const uint64_t cap = std::max<uint64_t>(256, (1ull << 28) / pl->n);
