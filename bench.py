@@ -428,8 +428,16 @@ class Workload:
                 f"frames and rows resident in HBM")
 
 
-def roofline_of(timing, steps):
-    dom = max(timing.items(), key=lambda kv: kv[1]["total_ms"])
+def roofline_of(timing, steps, dt=None):
+    """the dominant kernel: the largest summed launch time.  When kernels shared the chip (`kernels_overlap`: K1 beside the previous
+    IF's digitiser) a launch duration of those two is time on a SHARE of the CUs and of HBM, not time the kernel cost the step: they
+    are priced together (`overlapped_pair`), and the dominant kernel is the one with the most time of the chip to itself"""
+    cand = timing
+    if dt is not None and kernels_overlap(timing, steps, dt):
+        alone = {k: v for k, v in timing.items() if not (k.startswith("frbch_k1_") or k.startswith("frbch_quantise"))}
+        if alone:
+            cand = alone
+    dom = max(cand.items(), key=lambda kv: kv[1]["total_ms"])
     name, rec = dom
     ach = rec["algorithmic_bytes"] / (rec["total_ms"] * 1e-3) / 1e9 if rec["total_ms"] > 0 else 0.0
     return name, rec, ach
@@ -705,7 +713,7 @@ def main():
                 t2 = w2.timing()
                 st2 = w2.steady_state(args.config_steps)
                 v2 = w2.samples_per_step * args.config_steps / d2 / 1e6
-                nm, rec, ach = roofline_of(t2, args.config_steps)
+                nm, rec, ach = roofline_of(t2, args.config_steps, d2)
                 bps = budget_bytes_per_sample(sp)
                 configs[name] = {"workload": w2.describe(1), "value": round(v2, 1), "unit": "Msamples/s", "steps": args.config_steps,
                                  "ms_per_step": round(d2 / args.config_steps * 1e3, 4), "steady_state": round(st2, 1),
@@ -719,7 +727,7 @@ def main():
     if rank == 0:
         total_samples = samples_per_step * args.steps * world
         value = total_samples / dt / 1e6
-        name, rec, ach = roofline_of(timing, args.steps)
+        name, rec, ach = roofline_of(timing, args.steps, dt)
         # measured HBM bytes per launch of that kernel: live PMC passes of this run (collect_traffic), never a stored constant
         traffic = None
         if live_traffic and name in live_traffic:
@@ -743,6 +751,9 @@ def main():
                                    "achieved": round(v["algorithmic_bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1),
                                    "frac": round(v["algorithmic_bytes"] / (v["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                                for k, v in timing.items() if v["launches"] and v["total_ms"] > 0},
+                "dominance_rule": ("largest summed launch time" if not kernels_overlap(timing, args.steps, dt) else
+                                   "largest summed launch time among the kernels that had the chip to themselves; K1 and the digitiser ran "
+                                   "side by side and are priced together in `overlapped_pair` (each one's own figures: `per_kernel`)"),
                 "concurrency": concurrency_note(timing, args.steps, dt),
                 "overlapped_pair": overlapped_pair(timing, args.steps, dt),
                 "valu": valu,
