@@ -95,6 +95,37 @@ def test_rescale_and_digitiser_are_bit_exact_on_the_hip_floats(hip_lib, bw, ncha
     np.testing.assert_allclose(sc_out, 1.0 / np.sqrt(var), rtol=2e-6)
 
 
+@pytest.mark.parametrize("bw,pol,gain", [(32.0, 5, 40.0), (-32.0, 2, 0.02), (32.0, 4, 7.0)])
+def test_digitiser_clips_at_both_ends_exactly(hip_lib, bw, pol, gain):
+    """the 8-bit digitiser of the fast kernels (one add under round-toward-minus-infinity + v_floor + the saturating
+    v_cvt_pk_u8_f32, tools/micro/cvt_probe) with a scale that drives most values into the clips (x 40: Q / U / V far below 0 and
+    far above 255) or squeezes them onto a few codes (x 0.02): zero differing codes against the oracle's digitiser on identical floats"""
+    nchan, secs = 1024, 0.27
+    raw = synth.make_vdif(secs, bw_mhz=abs(bw), nchan=nchan)
+    d_raw = DeviceBuffer.from_numpy(raw)
+    nfr = raw.size // 8032
+    with ch.Channeliser(pu.lib_cfg(hip_lib, bw, nchan, secs, pol=pol, nbit=8), hip_lib) as c:
+        info = c.info
+        nblocks = (nfr * 8000) // info.block_payload_bytes
+        rows = nblocks * info.rows_per_block
+        pw = DeviceBuffer(rows * info.nif * nchan * 4)
+        c.power_device(d_raw.ptr.value, nfr, 8032, 32, 0, nblocks, pw.ptr.value, pw.nbytes)
+        power = pw.to_numpy(np.float32).reshape(rows, info.nif, nchan)
+        out = DeviceBuffer(rows * info.row_bytes)
+        r1 = c.process_device(d_raw.ptr.value, nfr, 8032, 32, 0, nblocks, out.ptr.value, out.nbytes)
+        r1 += c.flush_device(out.ptr.value + r1 * info.row_bytes, out.nbytes - r1 * info.row_bytes)
+        off, sc = c.get_rescale()
+        sc = (sc * np.float32(gain)).astype(np.float32)
+        c.reset()
+        c.set_rescale(off, sc)
+        assert c.process_device(d_raw.ptr.value, nfr, 8032, 32, 0, nblocks, out.ptr.value, out.nbytes) == rows
+        got = _unpack_codes(out.to_numpy(np.uint8), 8, (rows, info.nif, nchan))
+    want = _codes_from_hip_floats(power, off, sc, 8, usb=bw > 0)
+    assert np.count_nonzero(got != want) == 0
+    if gain > 1:
+        assert (got == 0).mean() > 0.02 and (got == 255).mean() > 0.02          # both clips are exercised
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # A4: every byte value, every decoder
 # ------------------------------------------------------------------------------------------------------------------
