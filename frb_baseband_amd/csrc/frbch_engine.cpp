@@ -124,6 +124,7 @@ struct frbch_handle {
   uint8_t* stg_cur = nullptr;      // staged payload of the launch in progress (stg + region offset)
   int lane_cus = 0;                // compute units of the stream the next K1 goes to (0 = all of them)
   int lane_ncu = 0;                // compute units of the device (frbch_open)
+  bool quant_lds_allowed = false;  // the digitiser's LDS reservation (overlap mode 3) was enabled on this handle's device
   dev_event_t region_ev[8];        // recorded behind the last back stage that read spill region r
   bool region_busy[8] = {false, false, false, false, false, false, false, false};
   bool region_ev_made = false;
@@ -1144,8 +1145,10 @@ int run_quantise(frbch_handle* h, uint64_t rows, uint8_t* dst, dev_stream_t s, i
       h->kname[KID_QUANT] = "frbch_quantise_fast<8>";
       if (excl) {
         constexpr size_t kHold = 84 * 1024;
-        static const int allowed = dev_allow_lds(fast::frbch_quantise_fast<8, 512>, kHold);
-        CHECK_DEV(h, allowed, "LDS size digitiser");
+        if (!h->quant_lds_allowed) {   // (per handle: the attribute belongs to the handle's device)
+          CHECK_DEV(h, dev_allow_lds(fast::frbch_quantise_fast<8, 512>, kHold), "LDS size digitiser");
+          h->quant_lds_allowed = true;
+        }
         hipLaunchKernelGGL((fast::frbch_quantise_fast<8, 512>), dim3(qp.grid_x), dim3(512), kHold, s, qp);
       } else {
         hipLaunchKernelGGL((fast::frbch_quantise_fast<8, 256>), dim3(qp.grid_x), dim3(256), 0, s, qp);
