@@ -339,7 +339,11 @@ void launch_k1_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s, i
     // 160 CUs): split the blocks over ny workgroups per group so that ngrp * ny fills whole rounds
     uint32_t g = ngrp, r = resident;
     while (r) { const uint32_t t = g % r; g = r; r = t; }
-    const uint32_t want = resident / g;
+    uint32_t want = resident / g;
+#ifdef FRBCH_EXPERIMENTS
+    static const int ny_env = getenv("FRBCH_K1_NY") ? atoi(getenv("FRBCH_K1_NY")) : 0;
+    if (ny_env > 0) want = (uint32_t)ny_env;
+#endif
     if (want <= nb) ny = want;
   }
 #define FRBCH_K1W(L, NWV, WPSV, NTV)                                                                                       \
