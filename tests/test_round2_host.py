@@ -246,3 +246,37 @@ def test_bench_maps_profiler_kernel_names_to_timing_slots():
         assert bench.short_kernel_name(name) == want, name
     # the slot names of the engine for the headline workload, as bench.py looks them up
     assert bench.short_kernel_name("void fast::frbch_k1_wave<3, 8, 1, true, false>(KParams)") in bench.VALU_PER_WAVE_BLOCK
+
+
+def test_bench_dominant_kernel_rule_with_and_without_overlap():
+    """bench.py: kernels one after the other -> the dominant kernel is the one with the largest summed launch time; when the
+    per-kernel times add up to more than the step (K1 beside the previous IF's digitiser), K1 and the digitiser are priced together
+    (`overlapped_pair`) and the dominant kernel is the one with the most time of the chip to itself"""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    try:
+        import bench
+    finally:
+        sys.path.remove(root)
+    rec = lambda ms, gb: {"launches": 8, "total_ms": ms, "algorithmic_bytes": gb * 1e9}
+    serial = {"frbch_k1_wave<3,8,1>": rec(12.4, 43.4), "frbch_k2_wave<3,4,4,2>": rec(15.0, 81.6), "frbch_quantise_fast<8>": rec(9.4, 51.0),
+              "frbch_k0_stage": rec(0.9, 5.1)}
+    dt = 0.0385     # 38.5 ms: the kernels add up to 37.7
+    assert not bench.kernels_overlap(serial, 1, dt)
+    name, r, ach = bench.roofline_of(serial, 1, dt)
+    assert name == "frbch_k2_wave<3,4,4,2>" and abs(ach - 81.6 / 15.0e-3) < 1e-6
+    assert bench.overlapped_pair(serial, 1, dt) is None
+    shared = dict(serial)
+    shared["frbch_k1_wave<3,8,1>"] = rec(18.2, 43.4)
+    shared["frbch_quantise_fast<8>"] = rec(18.0, 51.0)
+    dt = 0.0363     # 36.3 ms per step although the kernels add up to 52
+    assert bench.kernels_overlap(shared, 1, dt)
+    name, r, ach = bench.roofline_of(shared, 1, dt)
+    assert name == "frbch_k2_wave<3,4,4,2>"
+    pair = bench.overlapped_pair(shared, 1, dt)
+    assert pair["kernels"] == ["frbch_k1_wave<3,8,1>", "frbch_quantise_fast<8>"]
+    assert abs(pair["achieved"] - (43.4 + 51.0) / 18.2e-3) < 0.1 and 0 < pair["frac"] < 1
+    assert "side by side" in bench.concurrency_note(shared, 1, dt) or "beside" in bench.concurrency_note(shared, 1, dt)
+    # without the step time the plain rule applies
+    assert bench.roofline_of(shared, 1)[0] == "frbch_k1_wave<3,8,1>"
