@@ -249,8 +249,11 @@ def collect_traffic(argv):
     import shutil
     import subprocess
     import tempfile
-    if not shutil.which("rocprofv3"):
+    def why(msg):     # roofline.traffic is null then; say why on stderr
+        print("bench.py: live PMC pass: " + msg, file=sys.stderr)
         return None
+    if not shutil.which("rocprofv3"):
+        return why("rocprofv3 not found")
     child = [a for a in argv if a not in ("--pmc-child",)]
     res = {}
     tmp = tempfile.mkdtemp(prefix="frbch_pmc_", dir="/tmp")
@@ -263,7 +266,7 @@ def collect_traffic(argv):
             # own process group: on a timeout the profiler AND the python it started (which holds the GPU) are killed
             pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
             try:
-                rc = pr.wait(timeout=240)
+                rc = pr.wait(timeout=420)   # (the first `import torch` on a fresh box alone can take 1 - 2 minutes)
             except subprocess.TimeoutExpired:
                 import signal
                 try:
@@ -271,12 +274,11 @@ def collect_traffic(argv):
                 except OSError:
                     pass
                 pr.wait()
-                return None
-            if rc != 0:
-                return None
+                return why(cnt + ": timed out")
+            # (a profiler that fails at EXIT has still written its counters: judge by the files, not by the status)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if not files:
-                return None
+                return why("%s: no counter file (profiler exit status %s)" % (cnt, rc))
             for path in files:
                 for row in csv.DictReader(open(path)):
                     if row.get("Counter_Name") != cnt or "frbch" not in row.get("Kernel_Name", ""):
@@ -285,8 +287,8 @@ def collect_traffic(argv):
                     rec = res.setdefault(k, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "n": {}})
                     rec[cnt] += float(row["Counter_Value"])
                     rec["n"][cnt] = rec["n"].get(cnt, 0) + 1
-    except Exception:
-        return None
+    except Exception as exc:
+        return why(repr(exc))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     out = {"_source": "live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run (KB counters; wide fetches x2)"}
