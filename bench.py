@@ -4,14 +4,23 @@
 One "step" = one pass of the whole hot path (frame parse + 2-bit unpack -> filterbank -> detect ->
 tscrunch -> rescale -> 8-bit digitise) over one batch of synthetic per-IF VDIF that is already
 resident in HBM, through the C ABI (include/frbch.h).  Workload at N=1 is BASELINE.json
-configs[1]: 1 IF, 32 MHz, 2-bit dual-pol -> 1024-channel Stokes-I (digifil flags
-`-c -b8 -d1 -F1024:2048`, process_vdif.py:157-171).  With N GPUs every rank owns one IF (the
-path shards by IF, base2fil.sh:60-66: no collective on the data path) -> weak scaling.
+configs[2], the largest single-GPU configuration: 8 IFs x 32 MHz, 2-bit dual-pol -> 1024-channel
+full-Stokes IQUV on one GPU (per IF the digifil flags `-c -b8 -d4 -F1024:2048`,
+process_vdif.py:157-171), all IFs into ONE row buffer through frbch_scan_device.  With N GPUs every
+rank owns its own 8 IFs (the path shards by IF, base2fil.sh:60-66: no collective on the data path)
+-> weak scaling.  The other BASELINE configurations ride in the same line under "configs".
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  "roofline":       dominant kernel's algorithmic bytes / its HIP-event time vs the 8 TB/s HBM peak; "traffic" = HBM bytes
-                    per launch of that kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE: separate passes, gfx950
-                    x2 correction of wide fetches) collected LIVE by child processes of this very run (N = 1), else null
+  "roofline":       the SURVEY 8(d) figure.  `achieved` / `frac` = WHOLE PATH: value x the 8(d) budget bytes per sample
+                    (0.502 in + 8 + 8 spill + output codes; 18.5 B for four 8-bit products) against the 8 TB/s HBM peak --
+                    reproducible from the driver's own clock as budget x samples_per_step / ms_per_step.  `kernel*` = the
+                    kernel with the largest summed launch time (no exclusions), priced with ITS share of that budget (K1
+                    0.502 + 8, K2 8 + output codes, digitiser / statistics / K0 nothing) over its HIP-event time.
+                    `traffic` = HBM bytes of ALL kernels of one step from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE:
+                    separate passes, gfx950 x2 correction of wide fetches) collected LIVE by child processes of this very
+                    run (N = 1), else null; `traffic_ratio` = that over budget x samples_per_step.  The per-kernel byte
+                    model of the engine (which counts the fp32 rows of a buffered rescale interval as a kernel's own
+                    bytes) is kept apart as `kernel_model_frac` / `per_kernel`.
   "cpu_baseline":   the CPU oracle port timed on a bounded sample of the same workload (rank 0, N=1)
   "host_inclusive": the product call the reference makes (frbch_run_file: VDIF file -> .fil file, both on tmpfs) for the
                     same workload, PCIe both ways included -- never `value`
@@ -111,6 +120,8 @@ def cpu_baseline(seconds_budget: float, bw: float, nchan: int, pol: int = 2):
             rates = [float(pr.communicate(timeout=seconds_budget * 4 + 120)[0].strip().splitlines()[-1]) for pr in procs]
             res["all_cores"] = {"value": sum(rates) / 1e6, "unit": "Msamples/s", "cores": ncpu,
                                 "sample": f"{ncpu} single-threaded processes, one IF each, {seconds_budget / 2:g} s"}
+            res["all_cores_value"] = sum(rates) / 1e6       # (flat copies: BASELINE.md section 3 asks for both figures)
+            res["all_cores_n"] = ncpu
         except Exception as exc:   # reported baseline only: never fail the bench for it
             res["all_cores"] = {"error": str(exc)}
         return res
@@ -433,19 +444,33 @@ class Workload:
                 f"frames and rows resident in HBM")
 
 
-def roofline_of(timing, steps, dt=None):
-    """the dominant kernel: the largest summed launch time.  When kernels shared the chip (`kernels_overlap`: K1 beside the previous
-    IF's digitiser) a launch duration of those two is time on a SHARE of the CUs and of HBM, not time the kernel cost the step: they
-    are priced together (`overlapped_pair`), and the dominant kernel is the one with the most time of the chip to itself"""
-    cand = timing
-    if dt is not None and kernels_overlap(timing, steps, dt):
-        alone = {k: v for k, v in timing.items() if not (k.startswith("frbch_k1_") or k.startswith("frbch_quantise"))}
-        if alone:
-            cand = alone
-    dom = max(cand.items(), key=lambda kv: kv[1]["total_ms"])
-    name, rec = dom
-    ach = rec["algorithmic_bytes"] / (rec["total_ms"] * 1e-3) / 1e9 if rec["total_ms"] > 0 else 0.0
-    return name, rec, ach
+def budget_share_bytes_per_sample(name, spec):
+    """a kernel's share of the SURVEY 8(d) budget, bytes per dual-pol sample: the compulsory input and the spill write belong to
+    K1, the spill read and the output codes to K2 (the coherent path spills twice: K2c reads and writes, K3 reads, K4 emits);
+    K0's corner-turned copy, the statistics and the digitiser of a buffered rescale interval move bytes the budget does not hold"""
+    nprod = 4 if spec["pol"] >= 4 else 1
+    out = nprod / (2.0 * spec["tscrunch"])
+    if name.startswith("frbch_k1_"):
+        return 0.502 + 8.0
+    if name.startswith("frbch_k2c_"):
+        return 16.0
+    if name.startswith("frbch_k2_"):
+        return 8.0 + (0.0 if spec["coherent"] else out)
+    if name.startswith("frbch_k3_"):
+        return 8.0
+    if name.startswith("frbch_k4_"):
+        return out
+    return 0.0
+
+
+def roofline_of(timing, spec, samples):
+    """the dominant kernel = the largest summed launch time, no exclusions; `samples` = dual-pol samples of the measured steps.
+    Returns (name, record, GB/s of its 8(d) share, GB/s of the engine's own per-launch byte model)"""
+    name, rec = max(timing.items(), key=lambda kv: kv[1]["total_ms"])
+    sec = rec["total_ms"] * 1e-3
+    share = budget_share_bytes_per_sample(name, spec) * samples / sec / 1e9 if sec > 0 else 0.0
+    model = rec["algorithmic_bytes"] / sec / 1e9 if sec > 0 else 0.0
+    return name, rec, share, model
 
 
 def kernels_overlap(timing, steps, dt):
@@ -456,29 +481,23 @@ def kernels_overlap(timing, steps, dt):
 def concurrency_note(timing, steps, dt):
     if not kernels_overlap(timing, steps, dt):
         return "kernels run one after the other on the whole chip"
-    return ("in a scan the first-interval digitiser of IF i (frbch_quantise_fast, on CUs it holds by an LDS reservation, own plain "
-            "stream) runs beside the K1 of IF i + 1 (frbch_config.overlap automatic = mode 3, DESIGN.md section 4b): a kernel's launch "
-            "duration is its time on ITS share of the chip and of HBM, and the sum over kernels exceeds ms_per_step; `overlapped_pair` "
-            "prices the two together")
+    return ("kernels of consecutive IFs of a scan share the chip on plain streams (DESIGN.md section 4b): a kernel's launch duration is "
+            "its time on ITS share of the chip and of HBM, and the sum over kernels exceeds ms_per_step")
 
 
-def overlapped_pair(timing, steps, dt):
-    """K1 and the digitiser while they share the chip: their algorithmic bytes over the longer of the two totals (the first K1 and
-    the last digitiser of a step run alone: approximate by that much)"""
-    if not kernels_overlap(timing, steps, dt):
-        return None
-    k1 = [k for k in timing if k.startswith("frbch_k1_")]
-    q = [k for k in timing if k.startswith("frbch_quantise")]
-    if not k1 or not q:
-        return None
-    a, b = timing[k1[0]], timing[q[0]]
-    ms = max(a["total_ms"], b["total_ms"])
-    if ms <= 0:
-        return None
-    gbs = (a["algorithmic_bytes"] + b["algorithmic_bytes"]) / (ms * 1e-3) / 1e9
-    return {"kernels": [k1[0], q[0]], "ms_per_step": round(ms / steps, 4),
-            "algorithmic_bytes_per_step": (a["algorithmic_bytes"] + b["algorithmic_bytes"]) / steps,
-            "achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+def step_traffic(live_traffic, timing, steps):
+    """HBM bytes of all kernels of ONE step: live PMC bytes per launch (collect_traffic) x launches per step of the timed run"""
+    if not live_traffic:
+        return None, None
+    total, missing = 0.0, []
+    for k, v in timing.items():
+        if not v["launches"]:
+            continue
+        if k in live_traffic:
+            total += live_traffic[k] * v["launches"] / steps
+        else:
+            missing.append(k)
+    return total, missing
 
 
 def host_inclusive(args, torch, dist, wl, rank, world):
@@ -718,12 +737,13 @@ def main():
                 t2 = w2.timing()
                 st2 = w2.steady_state(args.config_steps)
                 v2 = w2.samples_per_step * args.config_steps / d2 / 1e6
-                nm, rec, ach = roofline_of(t2, args.config_steps, d2)
+                nm, rec, ach, _model = roofline_of(t2, sp, w2.samples_per_step * args.config_steps)
                 bps = budget_bytes_per_sample(sp)
                 configs[name] = {"workload": w2.describe(1), "value": round(v2, 1), "unit": "Msamples/s", "steps": args.config_steps,
                                  "ms_per_step": round(d2 / args.config_steps * 1e3, 4), "steady_state": round(st2, 1),
-                                 "dominant": nm, "frac": round(ach / HBM_PEAK_GBS, 4),
-                                 "whole_path_frac": round(v2 * 1e6 * bps / 1e9 / HBM_PEAK_GBS, 4),
+                                 "frac": round(v2 * 1e6 * bps / 1e9 / HBM_PEAK_GBS, 4),      # whole path, SURVEY 8(d) budget
+                                 "steady_state_frac": round(st2 * 1e6 * bps / 1e9 / HBM_PEAK_GBS, 4),
+                                 "dominant": nm, "dominant_frac": round(ach / HBM_PEAK_GBS, 4),   # its share of that budget / its time
                                  "kernels_ms_per_step": {k: round(v["total_ms"] / args.config_steps, 4) for k, v in t2.items() if v["launches"]}}
                 w2.close()
             except Exception as exc:   # reported extras: never fail the bench for them
@@ -739,7 +759,7 @@ def main():
             bps = budget_bytes_per_sample(sp)
             configs[args.workload + "_60s"] = {"workload": w2.describe(1), "value": round(v2, 1), "unit": "Msamples/s", "steps": 2,
                                                "ms_per_step": round(d2 / 2 * 1e3, 4),
-                                               "whole_path_frac": round(v2 * 1e6 * bps / 1e9 / HBM_PEAK_GBS, 4),
+                                               "frac": round(v2 * 1e6 * bps / 1e9 / HBM_PEAK_GBS, 4),
                                                "kernels_ms_per_step": {k: round(v["total_ms"] / 2, 4) for k, v in t2.items() if v["launches"]}}
             w2.close()
         except Exception as exc:
@@ -748,11 +768,12 @@ def main():
     if rank == 0:
         total_samples = samples_per_step * args.steps * world
         value = total_samples / dt / 1e6
-        name, rec, ach = roofline_of(timing, args.steps, dt)
-        # measured HBM bytes per launch of that kernel: live PMC passes of this run (collect_traffic), never a stored constant
-        traffic = None
-        if live_traffic and name in live_traffic:
-            traffic = live_traffic[name]
+        samples_timed = samples_per_step * args.steps                      # this rank's samples of the timed region
+        name, rec, ach, model = roofline_of(timing, spec, samples_timed)
+        bps = budget_bytes_per_sample(spec)
+        whole = value / world * 1e6 * bps / 1e9                            # GB/s of SURVEY 8(d) bytes, per GPU
+        # measured HBM bytes of ALL kernels of one step: live PMC passes of this run (collect_traffic), never a stored constant
+        traffic, traffic_missing = step_traffic(live_traffic, timing, args.steps)
         valu = None
         if name in VALU_PER_WAVE_BLOCK and rec["total_ms"] > 0:     # the other roof of this kernel: fp32 VALU lane operations
             per_wave, waves = VALU_PER_WAVE_BLOCK[name]
@@ -760,27 +781,31 @@ def main():
             tl = lane_ops / (rec["total_ms"] * 1e-3) / 1e12
             valu = {"bound": "valu", "achieved": round(tl, 2), "peak": VALU_PEAK_TLOPS, "unit": "T lane-ops/s (fp32, unpacked)",
                     "frac": round(tl / VALU_PEAK_TLOPS, 4), "instructions_per_wave_and_block": per_wave}
-        bps = budget_bytes_per_sample(spec)
-        roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "traffic_source": (live_traffic or {}).get("_source"),
-                "avg_launch_ms": round(rec["total_ms"] / max(1, rec["launches"]), 5),
-                "launches_per_step": rec["launches"] / args.steps,
-                "algorithmic_bytes_per_launch": rec["algorithmic_bytes"] / max(1, rec["launches"]),
+        share = budget_share_bytes_per_sample(name, spec)
+        roof = {"bound": "hbm", "scope": "whole path: value x SURVEY 8(d) budget bytes per sample (kernel_* = the dominant kernel with its share of it)",
+                "achieved": round(whole, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(whole / HBM_PEAK_GBS, 5),
+                "algorithmic_bytes_per_sample": round(bps, 3),
+                "algorithmic_bytes_per_step": bps * samples_per_step,
+                "traffic": traffic, "traffic_ratio": (round(traffic / (bps * samples_per_step), 4) if traffic else None),
+                "traffic_source": (live_traffic or {}).get("_source"), "traffic_kernels_without_counters": traffic_missing,
+                "kernel": name, "kernel_frac": round(ach / HBM_PEAK_GBS, 5), "kernel_achieved": round(ach, 2),
+                "kernel_budget_bytes_per_sample": share,
+                "kernel_avg_launch_ms": round(rec["total_ms"] / max(1, rec["launches"]), 5),
+                "kernel_launches_per_step": rec["launches"] / args.steps,
+                "kernel_budget_bytes_per_launch": share * samples_timed / max(1, rec["launches"]),
+                "kernel_model_frac": round(model / HBM_PEAK_GBS, 5),     # the engine's own byte model of that kernel (float rows of a buffered interval included)
+                "kernel_traffic_per_launch": (live_traffic or {}).get(name),
+                "steady_state_frac": round(steady * 1e6 * bps / 1e9 / HBM_PEAK_GBS, 5),
+                "valu_frac": (valu or {}).get("frac"),
+                "dominance_rule": "largest summed launch time (HIP events on the launch streams), no exclusions",
+                "concurrency": concurrency_note(timing, args.steps, dt),
                 "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in timing.items() if v["launches"]},
                 "per_kernel": {k: {"ms_per_step": round(v["total_ms"] / args.steps, 4),
-                                   "achieved": round(v["algorithmic_bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1),
-                                   "frac": round(v["algorithmic_bytes"] / (v["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                                   "budget_frac": round(budget_share_bytes_per_sample(k, spec) * samples_timed / (v["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "model_frac": round(v["algorithmic_bytes"] / (v["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "traffic_per_launch": (live_traffic or {}).get(k)}
                                for k, v in timing.items() if v["launches"] and v["total_ms"] > 0},
-                "dominance_rule": ("largest summed launch time" if not kernels_overlap(timing, args.steps, dt) else
-                                   "largest summed launch time among the kernels that had the chip to themselves; K1 and the digitiser ran "
-                                   "side by side and are priced together in `overlapped_pair` (each one's own figures: `per_kernel`)"),
-                "concurrency": concurrency_note(timing, args.steps, dt),
-                "overlapped_pair": overlapped_pair(timing, args.steps, dt),
-                "valu": valu,
-                "whole_path": {"algorithmic_bytes_per_sample": round(bps, 3),
-                               "achieved": round(value / world * 1e6 * bps / 1e9, 1),
-                               "frac": round(value / world * 1e6 * bps / 1e9 / HBM_PEAK_GBS, 4)}}
+                "valu": valu}
         line = {
             "metric": "Msamples/s channelised to .fil per GPU; achieved HBM GB/s vs peak",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,

@@ -1193,6 +1193,10 @@ void chain_quant_done(Chain* c, dev_stream_t sq);
 int finalize_interval(frbch_handle* h, uint64_t stat_rows, uint8_t* d_out, size_t cap, uint64_t* rows_written,
                       dev_stream_t s0, Chain* ch = nullptr) {
   const Plan& pl = h->pl;
+  if (h->quant_busy) {   // a digitiser of the previous interval (and its move of the remaining rows) still works on the power buffer
+    (void)dev_stream_wait(s0, h->quant_ev);
+    h->quant_busy = false;
+  }
   int rc = run_stats(h, stat_rows, s0);
   if (rc) return rc;
   // the back lane when the digitiser can run beside the next K1 (on CUs it holds by an LDS reservation: only the lean kernel does that)
@@ -1258,11 +1262,21 @@ Lanes* get_lanes(int device, int ncu_front, bool plain = false) {
   Lanes* ln = new Lanes();
   g_lanes.push_back({{device, key}, ln});
   ln->ncu = dev_cu_count(device);
+  // (a failed creation leaves the entry with ok = false: the streams made so far are destroyed, later calls get nullptr)
+  auto three_plain = [&]() {
+    if (dev_stream_create(&ln->f) == 0 && dev_stream_create(&ln->b) == 0 && dev_stream_create(&ln->b2) == 0) return true;
+    if (ln->f) dev_stream_destroy(ln->f);
+    if (ln->b) dev_stream_destroy(ln->b);
+    if (ln->b2) dev_stream_destroy(ln->b2);
+    ln->f = ln->b = ln->b2 = 0;
+    (void)dev_last_error_string();
+    return false;
+  };
   if (plain && ln->ncu > 0) {
     // mode 3: plain streams (no CU masks: a masked queue costs every launch of the process 50 - 100 us while it is active,
     // profiles/NOTES.md); the digitiser claims its CUs by its LDS reservation, ncu_f is what is left for the K1 beside it
     if (ncu_front < 8 || ncu_front > ln->ncu - 8) return nullptr;
-    if (dev_stream_create(&ln->f) != 0 || dev_stream_create(&ln->b) != 0 || dev_stream_create(&ln->b2) != 0) return nullptr;
+    if (!three_plain()) return nullptr;
     ln->ncu_f = ncu_front;
     ln->ok = true;
     return ln;
@@ -1270,7 +1284,7 @@ Lanes* get_lanes(int device, int ncu_front, bool plain = false) {
   if (ncu_front >= ln->ncu && ln->ncu > 0) {
     // no partition: plain streams.  Kernels of the two lanes share every CU as far as its registers, LDS and wave slots go
     // (the digitiser's 4-wave workgroups fit beside the wave K1's eight 216-register waves: one per CU)
-    if (dev_stream_create(&ln->f) != 0 || dev_stream_create(&ln->b) != 0 || dev_stream_create(&ln->b2) != 0) return nullptr;
+    if (!three_plain()) return nullptr;
     ln->ncu_f = ln->ncu;
     ln->ok = true;
     return ln;
@@ -1281,6 +1295,10 @@ Lanes* get_lanes(int device, int ncu_front, bool plain = false) {
   for (int i = 0; i < ln->ncu; ++i) (i < ncu_front ? mf : mb)[(size_t)i >> 5] |= 1u << (i & 31);
   if (dev_stream_create_masked(&ln->f, mf.data(), words) != 0 || dev_stream_create_masked(&ln->b, mb.data(), words) != 0 ||
       dev_stream_create_masked(&ln->b2, mb.data(), words) != 0) {
+    if (ln->f) dev_stream_destroy(ln->f);
+    if (ln->b) dev_stream_destroy(ln->b);
+    if (ln->b2) dev_stream_destroy(ln->b2);
+    ln->f = ln->b = ln->b2 = 0;
     (void)dev_last_error_string();
     return nullptr;
   }
@@ -1962,6 +1980,9 @@ extern "C" int frbch_scan_device(frbch_handle* const* ifs, uint32_t nif, const v
     if (a.c != pl.c || a.nif != pl.nif || a.tscr != pl.tscr || a.row_bytes != pl.row_bytes || ifs[i]->cfg.nbit_out != h0->cfg.nbit_out ||
         ifs[i]->device != h0->device || a.block_stride_bytes != pl.block_stride_bytes || a.block_payload_bytes != pl.block_payload_bytes)
       return fail(h0, FRBCH_E_ARG, "the IFs of a scan must share device, nchan, freq_res, tscrunch, nbit and products");
+    // one chain serves all IFs: its mode, lane size and eligibility are taken from ifs[0], so the others must agree
+    if (ifs[i]->cfg.overlap != h0->cfg.overlap || ifs[i]->cfg.flags != h0->cfg.flags || a.in_bits != pl.in_bits || a.coherent != pl.coherent)
+      return fail(h0, FRBCH_E_ARG, "the IFs of a scan must share flags, overlap, input bits and the coherent setting");
   }
   if (row_pitch_bytes != (size_t)nif * pl.row_bytes) return fail(h0, FRBCH_E_ARG, "row_pitch_bytes must be nif * row_bytes of one IF");
   if (!d_rows) return fail(h0, FRBCH_E_ARG, "null row buffer");
@@ -2006,8 +2027,10 @@ extern "C" int frbch_scan_device(frbch_handle* const* ifs, uint32_t nif, const v
     (void)bits;
   }
   chain_end(&ch);
-  if (stream)
-    for (uint32_t i = 0; i < nif; ++i) mark_user_stream(ifs[i], s);
+  // every handle whose own stream is not `s` records the scan's work behind it: a later frbch_reset / get_rescale / set_rescale
+  // of that handle waits for this event, not only for its own (idle) stream -- with stream == NULL that is every IF but the first
+  for (uint32_t i = 0; i < nif; ++i)
+    if (stream || ifs[i] != h0) mark_user_stream(ifs[i], s);
   *rows_written = rows_min == UINT64_MAX ? 0 : rows_min;
   return rc;
 }

@@ -8,7 +8,9 @@
 //   frbch_join <out.fil> <piece_0> [<piece_1> ...]          pieces in descending frequency, any mix of files and FIFOs
 //
 // Output: the SIGPROC header of piece 0 with nchans = sum over the pieces, then rows [t][product][piece-major channels];
-// rows are cut to the shortest piece, as splice does.  nbits / nifs / tsamp must agree and tstart within half a sample.
+// rows are cut to the shortest piece, as splice does.  nbits / nifs / tsamp must agree, tstart within half a sample, and the
+// pieces must continue each other in frequency in the order given (same foff, fch1 of piece i = fch1 + nchans foff of piece
+// i - 1): a wrong order would otherwise produce a silently mislabelled IFall file.
 // One reader thread per piece (two row blocks in flight each) so that every producer is drained while the join writes.
 // Exit status 0 on success, 1 with the reason on stderr otherwise; a failing piece fails the run.
 #include <errno.h>
@@ -59,6 +61,8 @@ struct Header {
   size_t nchans_value_off = 0;  // offset of the 4-byte nchans value inside bytes
   int nchans = 0, nbits = 0, nifs = 1;
   double tsamp = 0.0, tstart = 0.0;
+  double fch1 = 0.0, foff = 0.0;   // centre of channel 0, channel step (MHz)
+  bool have_freq = false;
 };
 
 // keyword types of the SIGPROC header (the set frbch_host.cpp writes, plus the other standard ones)
@@ -114,6 +118,8 @@ bool read_header(int fd, Header* h, std::string* why) {
       memcpy(&v, h->bytes.data() + h->bytes.size() - 8, 8);
       if (key == "tsamp") h->tsamp = v;
       else if (key == "tstart") h->tstart = v;
+      else if (key == "fch1") { h->fch1 = v; h->have_freq = true; }
+      else if (key == "foff") h->foff = v;
     } else if (kind == 3) {
       std::string v;
       if (!rd_str(&v)) return false;
@@ -137,6 +143,7 @@ struct Piece {
   size_t rows[2] = {0, 0};        // whole rows in buf[k]
   int state[2] = {0, 0};          // 0 free, 1 filled
   bool eof = false, failed = false;
+  int err = 0;                    // errno of the failed read (errno is thread-local: the reader thread keeps it here)
   std::mutex m;
   std::condition_variable cv;
   std::thread th;
@@ -165,6 +172,18 @@ int main(int argc, char** argv) {
     const Header &a = pc[i].hdr, &b = pc[0].hdr;
     if (a.nbits != b.nbits || a.nifs != b.nifs || a.tsamp != b.tsamp) { fprintf(stderr, "frbch_join: %s: nbits / nifs / tsamp differ from the first piece\n", argv[2 + i]); return 1; }
     if (fabs(a.tstart - b.tstart) > 0.5 * b.tsamp / 86400.0) { fprintf(stderr, "frbch_join: %s: tstart differs from the first piece\n", argv[2 + i]); return 1; }
+    // the output keeps piece 0's header (fch1, foff) with nchans patched: that labels the channels correctly only when the pieces
+    // continue each other in frequency, in the order given: fch1_i = fch1_{i-1} + nchans_{i-1} foff, same foff (sign included)
+    if (i > 0 && a.have_freq && pc[i - 1].hdr.have_freq) {
+      const Header& q = pc[i - 1].hdr;
+      const double tol = 1e-6 * fabs(q.foff) + 1e-9;
+      if (fabs(a.foff - q.foff) > tol) { fprintf(stderr, "frbch_join: %s: foff %.9g differs from the previous piece's %.9g\n", argv[2 + i], a.foff, q.foff); return 1; }
+      const double want = q.fch1 + (double)q.nchans * q.foff;
+      if (fabs(a.fch1 - want) > 0.01 * fabs(q.foff)) {
+        fprintf(stderr, "frbch_join: %s: fch1 %.9g MHz does not continue the previous piece (expected %.9g): pieces out of order or not contiguous\n", argv[2 + i], a.fch1, want);
+        return 1;
+      }
+    }
     pc[i].seg = (size_t)a.nchans * (size_t)a.nbits / 8;
     pc[i].row_bytes = pc[i].seg * (size_t)a.nifs;
     line_out += pc[i].seg;
@@ -196,7 +215,9 @@ int main(int argc, char** argv) {
         }
         size_t got = 0;
         const bool ok = read_exact(p->fd, p->buf[k].data(), block_rows * p->row_bytes, &got);
+        const int err = ok ? 0 : errno;
         std::lock_guard<std::mutex> lk(p->m);
+        if (!ok) p->err = err;
         p->rows[k] = got / p->row_bytes;            // (a trailing partial row is dropped, as splice does)
         p->state[k] = 1;
         if (!ok) p->failed = true;
@@ -217,7 +238,7 @@ int main(int argc, char** argv) {
       Piece& p = pc[i];
       std::unique_lock<std::mutex> lk(p.m);
       p.cv.wait(lk, [&] { return p.state[k] == 1; });
-      if (p.failed) { fprintf(stderr, "frbch_join: read %s: %s\n", argv[2 + i], strerror(errno)); rc = 1; }
+      if (p.failed) { fprintf(stderr, "frbch_join: read %s: %s\n", argv[2 + i], strerror(p.err)); rc = 1; }
       rows = std::min(rows, p.rows[k]);
       if (p.rows[k] < block_rows) done = true;      // the shortest piece ends the output
     }

@@ -180,6 +180,37 @@ def test_scan_device_rows_are_the_splice_of_the_per_if_rows(emu_lib, kw):
         c.close()
 
 
+def _scan_null_stream_last_handle_first(lib, nchan=128, freq_res=512, pol=5, secs=0.05, nif_scan=3):
+    """A scan queued with stream == NULL runs on ifs[0]'s stream; the LAST handle is then read and reset first.  Its own stream
+    is idle, so without the scan's event recorded on it (frbch_scan_device marks every handle whose stream is not the scan's)
+    the reset would overwrite offset / scale while the scan's statistics and digitiser still run."""
+    raws = [synth.make_vdif(secs, bw_mhz=16.0, nchan=nchan, if_index=i) for i in range(nif_scan)]
+    chans = [ch.Channeliser(pu.lib_cfg(lib, 16.0, nchan, secs, pol=pol, freq_res=freq_res), lib) for _ in range(nif_scan)]
+    info = chans[0].info
+    nfr = raws[0].size // 8032
+    nblocks = (nfr * 8000 - info.block_payload_bytes) // info.block_stride_bytes + 1
+    rows = nblocks * info.rows_per_block
+    return raws, chans, info, nfr, nblocks, rows
+
+
+def test_scan_device_null_stream_then_last_handle_first(emu_lib):
+    raws, chans, info, nfr, nblocks, rows = _scan_null_stream_last_handle_first(emu_lib)
+    ptrs = [r.ctypes.data for r in raws]
+    bufs, scales = [], []
+    for _ in range(2):
+        buf = np.zeros(rows * len(chans) * info.row_bytes, np.uint8)
+        assert multi_if.scan_device(chans, ptrs, nfr, 8032, 32, 0, nblocks, buf.ctypes.data, rows, flush=True, stream=None) == rows
+        scales.append(chans[-1].get_rescale())          # the last handle first
+        for c in reversed(chans):
+            c.reset()
+        bufs.append(buf)
+    np.testing.assert_array_equal(bufs[0], bufs[1])
+    np.testing.assert_array_equal(scales[0][1], scales[1][1])
+    assert bufs[0].any()
+    for c in chans:
+        c.close()
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # the node-level scan: python -m frb_baseband_amd.scan = one rank process per GPU + the native streaming join
 # (base2fil.sh:30-67, 348-350, 404-448).  On CPU the ranks load the TEST-ONLY emulator build through FRBCH_LIB.
@@ -236,12 +267,14 @@ def test_node_scan_a_failing_rank_fails_the_run(emu_lib, tmp_path):
 
 
 def test_native_join_cuts_to_the_shortest_piece_and_checks_headers(emu_lib, tmp_path):
-    """frbch_join == multi_if.splice (the numpy restatement of sigproc splice) on files of unequal length"""
+    """frbch_join == multi_if.splice (the numpy restatement of sigproc splice) on files of unequal length; pieces that do not
+    continue each other in frequency (wrong order, a gap) are refused instead of being mislabelled"""
     d = str(tmp_path)
     pieces = []
-    for i, secs in ((1, 0.03), (2, 0.02), (3, 0.03)):
+    # three USB pieces of 16 MHz, highest first (base2fil.sh:350,367): centres 1640, 1624, 1608 MHz
+    for i, (secs, freq) in enumerate(((0.03, 1640.0), (0.02, 1624.0), (0.03, 1608.0)), start=1):
         raw = synth.make_vdif(secs, bw_mhz=16.0, nchan=32, if_index=i)
-        with ch.Channeliser(pu.lib_cfg(emu_lib, 16.0, 32, secs, pol=4, freq_res=64), emu_lib) as c:
+        with ch.Channeliser(pu.lib_cfg(emu_lib, 16.0, 32, secs, pol=4, freq_res=64, freq=freq), emu_lib) as c:
             p = os.path.join(d, f"p{i}.fil")
             open(p, "wb").write(c.channelise_bytes(raw))
             pieces.append(p)
@@ -250,7 +283,14 @@ def test_native_join_cuts_to_the_shortest_piece_and_checks_headers(emu_lib, tmp_
     pr = subprocess.run([join, out] + pieces, capture_output=True, text=True, timeout=120)
     assert pr.returncode == 0, pr.stderr
     assert open(out, "rb").read() == multi_if.splice(pieces)
-    with ch.Channeliser(pu.lib_cfg(emu_lib, 16.0, 32, 0.02, pol=2, freq_res=64), emu_lib) as c:
+    got = sigproc.read_fil(out)
+    assert got.header["nchans"] == 96 and got.header["fch1"] == pytest.approx(sigproc.read_fil(pieces[0]).header["fch1"])
+    # wrong order / a missing piece: the header of piece 0 would label the channels wrongly
+    pr = subprocess.run([join, out, pieces[1], pieces[0], pieces[2]], capture_output=True, text=True, timeout=120)
+    assert pr.returncode != 0 and "does not continue" in pr.stderr
+    pr = subprocess.run([join, out, pieces[0], pieces[2]], capture_output=True, text=True, timeout=120)
+    assert pr.returncode != 0 and "does not continue" in pr.stderr
+    with ch.Channeliser(pu.lib_cfg(emu_lib, 16.0, 32, 0.02, pol=2, freq_res=64, freq=1624.0), emu_lib) as c:
         other = os.path.join(d, "other.fil")
         open(other, "wb").write(c.channelise_bytes(synth.make_vdif(0.02, bw_mhz=16.0, nchan=32)))
     pr = subprocess.run([join, out, pieces[0], other], capture_output=True, text=True, timeout=120)
