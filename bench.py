@@ -236,7 +236,7 @@ def launch_ranks(args, argv):
     return 0
 
 
-WIDE_FETCH = ("frbch_k2_", "frbch_quantise", "frbch_stats_partial", "frbch_k0_stage", "frbch_k1_wave", "frbch_k1_split")
+WIDE_FETCH = ("frbch_k2_wave", "frbch_k2_fast", "frbch_k2_lane", "frbch_k2_scrunch", "frbch_k2c_", "frbch_quantise", "frbch_stats_partial", "frbch_k0_stage", "frbch_k1_wave", "frbch_k1_split")   # (frbch_k2_priv reads 8 bytes per lane: counted as it is)
 
 
 def short_kernel_name(profiler_name):
@@ -303,6 +303,7 @@ def collect_traffic(argv):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     out = {"_source": "live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run (KB counters; wide fetches x2)"}
+    total = 0.0
     for k, rec in res.items():
         short = short_kernel_name(k)
         if not short:
@@ -312,6 +313,9 @@ def collect_traffic(argv):
         out[short] = (rec["FETCH_SIZE"] / max(1, rec["n"].get("FETCH_SIZE", 1)) * corr +
                       rec["WRITE_SIZE"] / max(1, rec["n"].get("WRITE_SIZE", 1))) * 1024.0
         out.setdefault("_launches", {})[short] = nl
+        total += (rec["FETCH_SIZE"] * corr + rec["WRITE_SIZE"]) * 1024.0
+    # every frbch kernel of the child's two steps (one warm-up + one timed: --steps 1 --warmup 1), whatever its name: per step
+    out["_step_total"] = total / 2.0
     return out
 
 
@@ -497,6 +501,8 @@ def step_traffic(live_traffic, timing, steps):
             total += live_traffic[k] * v["launches"] / steps
         else:
             missing.append(k)
+    if "_step_total" in live_traffic:      # the sum over every kernel of the profiled steps (timing-slot names need not match the profiler's)
+        return live_traffic["_step_total"], []
     return total, missing
 
 

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FRBCH_LIB: another build of the same library for this process (the profiling build `make exp`); default: the product
 LIB_PATH = os.environ.get("FRBCH_LIB") or os.path.join(_HERE, "csrc", "libfrbch.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 OK, E_ARG, E_IO, E_FORMAT, E_DEVICE, E_NOMEM, E_STATE, E_CAPACITY = 0, -1, -2, -3, -4, -5, -6, -7
 
@@ -64,7 +64,7 @@ class _KTiming(C.Structure):
 
 
 class FrbchTiming(C.Structure):
-    _fields_ = [("size", C.c_uint32), ("nkernels", C.c_uint32), ("k", _KTiming * 8)]
+    _fields_ = [("size", C.c_uint32), ("nkernels", C.c_uint32), ("k", _KTiming * 12)]
 
 
 # every symbol include/frbch.h declares: (restype, argtypes)

@@ -33,15 +33,18 @@
 #include "kernels_generic.inc"
 #ifndef FRBCH_NO_FAST
 #include "kernels_fast.inc"
+#include "kernels_k2priv.inc"
 #endif
 
 using namespace frbch;
 
 namespace {
 
-enum { KID_K1 = 0, KID_KC, KID_K2, KID_STATS, KID_QUANT, KID_K3, KID_K4, KID_K0, KID_COUNT };
+enum { KID_K1 = 0, KID_KC, KID_K2, KID_STATS, KID_QUANT, KID_K3, KID_K4, KID_K0, KID_K2S, KID_COUNT };
 const char* const kKernelNames[KID_COUNT] = {"frbch_k1_branch", "frbch_kc_dcfix", "frbch_k2_chan",
-                                             "frbch_stats", "frbch_quantise", "frbch_k3_dedisp", "frbch_k4_out", "frbch_k0_stage"};
+                                             "frbch_stats", "frbch_quantise", "frbch_k3_dedisp", "frbch_k4_out", "frbch_k0_stage",
+                                             "frbch_k2_statpass"};
+static_assert(KID_COUNT <= (int)(sizeof(((frbch_timing*)nullptr)->k) / sizeof(((frbch_timing*)nullptr)->k[0])), "frbch_timing holds every slot");
 
 struct EventPair {
   dev_event_t a, b;
@@ -87,6 +90,16 @@ struct frbch_handle {
   int fused_chunks = 0;        // rows of `partial` the fused path uses (0 = this configuration cannot fuse)
 
   uint64_t rows_out = 0, blocks_done = 0;
+  // two-pass rescale: the first batch of a `-c` rescale interval is not written as float rows.  K2 runs over
+  // the resident spill twice instead -- a statistics-only pass at once, the digitising pass when the interval is complete (inside
+  // the batch, or at the flush).  Until then the batch is DEFERRED: its spill, S and dP stay untouched.
+  struct Deferred {
+    bool active = false;
+    KParams p;            // the batch's launch parameters as launch_front left them
+    uint32_t nb = 0;
+    uint64_t rows = 0;
+  } deferred;
+  int priv_grid = 0;              // workgroups of frbch_k2_priv (one per CU): its rows of partial rescale sums
 
   // VDIF stream state (host streaming path)
   bool have_vdif = false;
@@ -171,7 +184,7 @@ struct DeviceGuard {
 };
 
 // kernel-selection switches a product build accepts (include/frbch.h); everything else is an experiment
-constexpr uint32_t kProductFlags = 1u | 2u | 4u | 8u | 16u | 32u | 64u | 128u | (1u << 20) | (1u << 21) | (1u << 22) | (1u << 23) | (1u << 24) | (1u << 25);
+constexpr uint32_t kProductFlags = 1u | 2u | 4u | 8u | 16u | 32u | 64u | 128u | (1u << 20) | (1u << 21) | (1u << 22) | (1u << 23) | (1u << 24) | (1u << 25) | (1u << 26) | (1u << 27);
 constexpr uint32_t kFlagNoPipeline = 1u << 22, kFlagNoK0 = 1u << 23, kFlagGenericQuant = 1u << 25;
 #ifdef FRBCH_EXPERIMENTS
 constexpr uint32_t kAcceptedFlags = kProductFlags | 0x000FFF00u;
@@ -388,7 +401,27 @@ constexpr uint32_t kK3WaveWgs = 2048;
 bool k3_wave_planned(const Plan& pl, uint32_t h_flags) {
   return pl.coherent && pl.coh_fast_r == 4 && pl.coh_nt == 512 && !(h_flags & 8u);
 }
-int fused_stat_chunks(const Plan& pl, uint32_t h_flags, int pol_mode) {
+// frbch_k2_priv: one row of partial sums per (workgroup, row phase); `grid` = its workgroups (one per CU)
+int priv_stat_chunks(const Plan& pl, int grid) { return grid * (pl.ncol / 4 >= 256 ? 1 : (int)(256 / (pl.ncol / 4))); }
+// which K2 a launch of a plan with frbch_k2_priv takes: float rows of four products stay on frbch_k2_wave (measured, config 3:
+// 1.87 ms per IF against 1.97 -- the phase is HBM-bound and the two-wave kernel reads whole 128-byte lines, frbch_k2_priv halves of
+// them twice), everything else -- codes, one product, statistics only -- runs frbch_k2_priv (steady state of config 3 + 2.4 %,
+// config 2 + 4 %)
+bool pol_mode_no_sums(int pol_mode) { return pol_mode == 3; }   // (PP+QQ)^2: its square overflows the fp32 partial sums (~1e24 squared)
+bool priv_takes(const Plan& pl, const KParams& p, int priv_grid) {
+  // (the two-wave kernel reads the tile-major spill only in its two-sample form: fast_k2_nw == 2, tscrunch <= 2)
+  return pl.fast_k2_priv && p.tile_major == 2 && priv_grid > 0 &&
+         !(p.out_mode == FRBCH_OUT_FLOAT_POWER && pl.nif == 4 && pl.fast_k2_nw == 2 && pl.fast_k2_log2m == 3);
+}
+int wave_stat_chunks(const Plan& pl, uint32_t h_flags, int pol_mode);
+// rows of the table of partial rescale sums the kernels of this plan may write (both K2 families add into the same table: whatever
+// mix of them ran, frbch_stats_final sums every row)
+int fused_stat_chunks(const Plan& pl, uint32_t h_flags, int pol_mode, int priv_grid = 0) {
+  if (pol_mode == 3 || pl.k2_two_stage || (h_flags & (1u << 20))) return wave_stat_chunks(pl, h_flags, pol_mode);
+  const int w = wave_stat_chunks(pl, h_flags, pol_mode);
+  return (pl.fast_k2_priv && priv_grid > 0) ? std::max(w, priv_stat_chunks(pl, priv_grid)) : w;
+}
+int wave_stat_chunks(const Plan& pl, uint32_t h_flags, int pol_mode) {
   if (pol_mode == 3 || pl.k2_two_stage) return 0;   // (two-stage tscrunch: K2 does not see the output rows)
   if (k3_wave_planned(pl, h_flags)) return (h_flags & (1u << 20)) ? 0 : (int)kK3WaveWgs;   // (PP+QQ)^2: its square overflows the fp32 partial sums (~1e24 squared)
   if (!(pl.fast_k2_log2m || pl.fast_k2_m1) || !pl.fast_k2_wave || pl.coherent || (h_flags & (1u << 20))) return 0;
@@ -406,7 +439,7 @@ void launch_k2_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s, u
   const int spw = tps < 64 ? 64 / tps : 1;
   // persistent: one wave of workgroups loops over the (tiles per block) x nb tiles of the launch
   p.nblk = nb;
-  if (!fused_stat_chunks(pl, h_flags, p.pol_mode)) p.stat_partial = nullptr;
+  if (!wave_stat_chunks(pl, h_flags, p.pol_mode)) p.stat_partial = nullptr;
 #ifdef FRBCH_EXPERIMENTS
   static const uint32_t npers_env = getenv("FRBCH_K2_NPERS") ? (uint32_t)atoi(getenv("FRBCH_K2_NPERS")) : 0u;
 #else
@@ -616,6 +649,23 @@ bool launch_k2_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
 #undef FRBCH_K2L
     return true;
   }
+  if (priv_takes(pl, p, h->priv_grid)) {   // one wave per time sample (kernels_k2priv.inc)
+    KParams& k = p;
+    k.nblk = nb;
+    if (pol_mode_no_sums(k.pol_mode) || (h->cfg.flags & (1u << 20))) k.stat_partial = nullptr;
+    const uint64_t ntiles = (uint64_t)nb * (uint64_t)(pl.r / 4);
+    const dim3 grid((unsigned)std::min<uint64_t>(ntiles, (uint64_t)h->priv_grid));
+    const int pm = k.pol_mode == 2 ? 2 : (k.pol_mode >= 4 ? k.pol_mode : 0);
+    const size_t lds = pl.k2_priv_lds;
+#define FRBCH_K2P(PMV) do { \
+      if (k.out_mode == FRBCH_OUT_CODES) hipLaunchKernelGGL((fast::frbch_k2_priv<PMV, fast::K2P_CODES>), grid, dim3(256), lds, s, k); \
+      else if (k.out_mode == FRBCH_OUT_STATS) hipLaunchKernelGGL((fast::frbch_k2_priv<PMV, fast::K2P_STATS>), grid, dim3(256), lds, s, k); \
+      else hipLaunchKernelGGL((fast::frbch_k2_priv<PMV, fast::K2P_POWER>), grid, dim3(256), lds, s, k); } while (0)
+    if (pm == 2) FRBCH_K2P(2); else if (pm == 4) FRBCH_K2P(4); else if (pm == 5) FRBCH_K2P(5); else FRBCH_K2P(0);
+#undef FRBCH_K2P
+    return true;
+  }
+  if (p.out_mode == FRBCH_OUT_STATS) return false;   // (only frbch_k2_priv has a statistics-only form: the engine asks for it nowhere else)
   if (pl.fast_k2_wave) {
     // tscrunch beyond the kernel's tile: rows of its largest tile into the scratch buffer (q), then the sums (p)
     KParams q = p;
@@ -849,6 +899,15 @@ int setup_fast(frbch_handle* h) {
     }
     if (rc) return rc;
     const bool big = pl.fast_k2_nt == 1024;
+    if (pl.fast_k2_priv) {
+      rc = FRBCH_OK;
+#define FRBCH_ALLOWP(PMV) do { if (!rc) rc = allow_lds(h, fast::frbch_k2_priv<PMV, fast::K2P_CODES>, pl.k2_priv_lds); \
+                               if (!rc) rc = allow_lds(h, fast::frbch_k2_priv<PMV, fast::K2P_POWER>, pl.k2_priv_lds); \
+                               if (!rc) rc = allow_lds(h, fast::frbch_k2_priv<PMV, fast::K2P_STATS>, pl.k2_priv_lds); } while (0)
+      FRBCH_ALLOWP(0); FRBCH_ALLOWP(2); FRBCH_ALLOWP(4); FRBCH_ALLOWP(5);
+#undef FRBCH_ALLOWP
+      if (rc) return rc;
+    }
     if (pl.fast_k2_wave) {
       rc = FRBCH_OK;
 #define FRBCH_ALLOW_(L, NWV, PMV, W) if (!rc) rc = allow_lds(h, fast::frbch_k2_wave<L, NWV, PMV, W>, pl.k2_fast_lds)
@@ -977,6 +1036,12 @@ int launch_back(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   const bool k3_sums = false;
 #endif
   if ((!((pl.fast_k2_log2m || pl.fast_k2_m1) && pl.fast_k2_wave) || pl.coherent) && !k3_sums) p.stat_partial = nullptr;   // only the wave-private K2 / K3 sum while they write
+  if (p.out_mode == FRBCH_OUT_STATS) {   // first pass of the two-pass rescale: the spill is read, nothing but the sums is written
+    ProfScope ps(h, s, KID_K2S, (double)nb * (double)pl.n * 8.0);
+    if (!launch_k2_fast(h, p, nb, s)) return fail(h, FRBCH_E_STATE, "statistics-only K2 pass without frbch_k2_priv");
+    CHECK_DEV(h, dev_check_launch(), "launch K2 (statistics pass)");
+    return FRBCH_OK;
+  }
   if (pl.coherent) {   // K2c (branches -> channels, x kernel), K3 (back to time, detect), K4 (time-major rows)
     {
       ProfScope ps(h, s, KID_K2, (double)nb * (double)pl.n * 24.0);
@@ -1006,18 +1071,26 @@ int launch_back(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   return FRBCH_OK;
 }
 
-int ensure_powbuf(frbch_handle* h) {
-  if (h->powbuf) return FRBCH_OK;
+// the table of partial rescale sums (separate statistics pass: partial_chunks rows; sums fused into K2: fused_chunks rows)
+int ensure_partial(frbch_handle* h) {
+  if (h->partial) return FRBCH_OK;
   const Plan& pl = h->pl;
-  h->pow_cap_rows = pl.interval_rows + (uint64_t)pl.maxb * pl.rows_per_block;
-  CHECK_DEV(h, dev_malloc((void**)&h->powbuf, h->pow_cap_rows * pl.ncol * sizeof(float)), "hipMalloc(power buffer)");
   h->partial_chunks = 2048;
   h->fused_chunks = 0;
 #ifndef FRBCH_NO_FAST
-  h->fused_chunks = fused_stat_chunks(pl, h->cfg.flags, h->cfg.pol_mode);   // flag bit 20 forces the separate statistics pass
+  h->fused_chunks = fused_stat_chunks(pl, h->cfg.flags, h->cfg.pol_mode, h->priv_grid);   // flag bit 20 forces the separate statistics pass
 #endif
   const size_t chunks = (size_t)std::max(h->partial_chunks, h->fused_chunks);
   CHECK_DEV(h, dev_malloc((void**)&h->partial, chunks * pl.ncol * 2 * sizeof(double)), "hipMalloc(partials)");
+  return FRBCH_OK;
+}
+// the float rows of a buffered rescale interval (allocated on first use: a scan whose first interval takes the two-pass form never needs it)
+int ensure_powbuf(frbch_handle* h) {
+  const int rc = ensure_partial(h);
+  if (rc || h->powbuf) return rc;
+  const Plan& pl = h->pl;
+  h->pow_cap_rows = pl.interval_rows + (uint64_t)pl.maxb * pl.rows_per_block;
+  CHECK_DEV(h, dev_malloc((void**)&h->powbuf, h->pow_cap_rows * pl.ncol * sizeof(float)), "hipMalloc(power buffer)");
   return FRBCH_OK;
 }
 
@@ -1044,6 +1117,7 @@ int run_stats(frbch_handle* h, uint64_t rows, dev_stream_t s) {
     CHECK_DEV(h, dev_check_launch(), "launch stats (final)");
     return FRBCH_OK;
   }
+  if (!h->powbuf) return fail(h, FRBCH_E_STATE, "rescale statistics: neither fused sums nor buffered rows");
   sp.power = h->powbuf;
   sp.partial = h->partial;
   sp.rows = rows;
@@ -1237,6 +1311,62 @@ int finalize_interval(frbch_handle* h, uint64_t stat_rows, uint8_t* d_out, size_
 }
 
 bool fused_ok(const frbch_handle* h) { return h->scale_frozen; }
+
+// ---- two-pass rescale of a first interval (`-c`, which the reference always passes, process_vdif.py:157,160) -------------------
+// The buffered form writes the float rows of the interval (8 B per dual-pol sample with four products), reads them back in the
+// digitiser and moves 26 B per sample behind K1; with frbch_k2_priv the batch's spill is still resident when the interval is
+// complete, so K2 runs over it twice instead: a statistics-only pass (sums, no rows), frbch_stats_final, then the digitising pass --
+// 18 B per sample, and the SAME float arithmetic in both passes, so the codes are what the buffered form produces from the same
+// offset / scale.  Taken when the interval starts with this batch and either ends inside it or the batch is the last of the call
+// (the flush, or the next call, then finds the batch deferred).  MEASURED SLOWER than the buffered form (round 4):
+// both K2 passes are bound by their waves' instruction chains (~1.5 ms each per IF of config 3), while the buffered form's extra 16 B
+// per sample stream at 5.2 - 5.45 TB/s partly beside the next IF's K1.  Opt-in by flag bit 27; the default stays buffered.
+bool twopass_usable(const frbch_handle* h) {
+#ifndef FRBCH_NO_FAST
+  const Plan& pl = h->pl;
+  return pl.fast_k2_priv && h->priv_grid > 0 && h->cfg.rescale_constant && pl.interval_rows > 0 && !pl.k2_two_stage &&
+         (h->cfg.flags & (1u << 27)) && fused_stat_chunks(pl, h->cfg.flags, h->cfg.pol_mode, h->priv_grid) > 0;
+#else
+  return false;
+#endif
+}
+// second pass over a deferred batch: offset / scale are final, K2 digitises the batch's rows into d_out
+int deferred_emit(frbch_handle* h, uint8_t* d_out, size_t cap, uint64_t* rows_written, dev_stream_t s) {
+  frbch_handle::Deferred& d = h->deferred;
+  if (out_extent(h, *rows_written + d.rows) > cap) return fail(h, FRBCH_E_CAPACITY, "output buffer too small for the rows of a completed rescale interval");
+  KParams p = d.p;
+  p.offset = h->offset;
+  p.scale = h->scale;
+  p.out_mode = FRBCH_OUT_CODES;
+  p.code_out = d_out;
+  p.row0 = *rows_written;
+  p.out_pitch = h->out_pitch ? h->out_pitch : (uint64_t)h->pl.c;
+  p.stat_partial = nullptr;
+  const int rc = launch_back(h, p, d.nb, s);
+  if (rc) return rc;
+  *rows_written += d.rows;
+  h->rows_out += d.rows;
+  d.active = false;
+  return FRBCH_OK;
+}
+// more blocks arrive while a batch is deferred and its interval is still open: the batch becomes the front of the buffered
+// interval after all (one K2 pass writes its float rows; its sums are already in the partial table)
+int deferred_materialise(frbch_handle* h, dev_stream_t s) {
+  frbch_handle::Deferred& d = h->deferred;
+  int rc = ensure_powbuf(h);
+  if (rc) return rc;
+  if (d.rows > h->pow_cap_rows) return fail(h, FRBCH_E_STATE, "power buffer overflow");
+  KParams p = d.p;
+  p.out_mode = FRBCH_OUT_FLOAT_POWER;
+  p.power_out = h->powbuf;
+  p.row0 = 0;
+  p.stat_partial = nullptr;
+  rc = launch_back(h, p, d.nb, s);
+  if (rc) return rc;
+  h->pow_rows = d.rows;
+  d.active = false;
+  return FRBCH_OK;
+}
 
 // =============================================================================================
 // Two lanes.  The front half of a batch (K0, K1, Kc) is bound by the instruction chain of its
@@ -1581,6 +1711,9 @@ int engine_feed_run(frbch_handle* h, const uint8_t* d_frames, uint32_t frame_byt
   }
   const uint64_t spill_blk = (uint64_t)(pl.c2 / pl.g) * pl.gs;      // cf per block of the spill
   int rc = FRBCH_OK;
+  // a batch deferred by the two-pass rescale whose interval goes on: its float rows are written NOW, before the front stage of
+  // the next batch overwrites the spill they come from
+  if (h->deferred.active && !fused_ok(h)) rc = deferred_materialise(h, ch->user);
   for (uint64_t b0 = 0; b0 < nblocks && !rc; b0 += per) {
     const uint32_t nb = (uint32_t)std::min<uint64_t>(per, nblocks - b0);
     const uint32_t reg = (ch->ln && ch->mode == 1) ? (h->next_region++ % nreg) : 0;
@@ -1625,6 +1758,34 @@ int engine_feed_run(frbch_handle* h, const uint8_t* d_frames, uint32_t frame_byt
       if (rc) break;
       *rows_written += rows;
       h->rows_out += rows;
+    } else if (!h->deferred.active && h->pow_rows == 0 && twopass_usable(h) && p.tile_major == 2 &&
+               (rows >= pl.interval_rows || b0 + per >= nblocks)) {
+      // ---- two-pass rescale: statistics-only pass now, the digitising pass once the interval is complete ----------------------
+      rc = ensure_partial(h);
+      if (rc) break;
+      if (dev_memset(h->partial, 0, (size_t)h->fused_chunks * pl.ncol * 2 * sizeof(double), sb) != 0) { rc = fail(h, FRBCH_E_DEVICE, "clear partial sums"); break; }
+      p.out_mode = FRBCH_OUT_STATS;
+      p.row0 = 0;
+      p.stat_partial = h->partial;
+      p.stat_limit = pl.interval_rows;
+      rc = launch_back(h, p, nb, sb);
+      if (rc) break;
+      h->fused_rows = std::min<uint64_t>(rows, pl.interval_rows);
+      h->fused_valid = true;
+      h->deferred.active = true;
+      h->deferred.p = p;
+      h->deferred.nb = nb;
+      h->deferred.rows = rows;
+      if (rows >= pl.interval_rows) {   // the interval ends inside this batch: offset / scale now, then every row of the batch
+        rc = run_stats(h, pl.interval_rows, sb);
+        if (rc) break;
+        h->have_scale = true;
+        h->scale_frozen = true;        // (-c: twopass_usable)
+        h->fused_rows = 0;
+        h->fused_valid = false;
+        rc = deferred_emit(h, d_out, cap, rows_written, sb);
+        if (rc) break;
+      }
     } else {
       rc = ensure_powbuf(h);
       if (rc) break;
@@ -1669,6 +1830,15 @@ int engine_feed_run(frbch_handle* h, const uint8_t* d_frames, uint32_t frame_byt
 
 int engine_flush(frbch_handle* h, uint8_t* d_out, size_t cap, uint64_t* rows_written, dev_stream_t s, Chain* ch = nullptr) {
   *rows_written = 0;
+  if (h->deferred.active && !fused_ok(h)) {   // the scan ended inside its first interval: statistics over what there is, then the digitising pass
+    int rc = run_stats(h, h->deferred.rows, s);
+    if (rc) return rc;
+    h->have_scale = true;
+    if (h->cfg.rescale_constant) h->scale_frozen = true;
+    h->fused_rows = 0;
+    h->fused_valid = false;
+    return deferred_emit(h, d_out, cap, rows_written, s);
+  }
   if (fused_ok(h) || h->pow_rows == 0) return FRBCH_OK;
   if (h->quant_busy) {
     (void)dev_stream_wait(s, h->quant_ev);
@@ -1725,9 +1895,9 @@ static void mark_user_stream(frbch_handle* h, dev_stream_t s) {
 }
 
 #ifdef FRBCH_EXPERIMENTS
-extern "C" const char* frbch_version(void) { return "frbch abi 3 backend " FRBCH_BACKEND_NAME " +experiments"; }
+extern "C" const char* frbch_version(void) { return "frbch abi 4 backend " FRBCH_BACKEND_NAME " +experiments"; }
 #else
-extern "C" const char* frbch_version(void) { return "frbch abi 3 backend " FRBCH_BACKEND_NAME; }
+extern "C" const char* frbch_version(void) { return "frbch abi 4 backend " FRBCH_BACKEND_NAME; }
 #endif
 
 extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
@@ -1762,6 +1932,7 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
   const uint64_t nlo = 1ull << pl.log2_nlo, nhi = pl.n >> pl.log2_nlo;
   if ((rc = upload_table(h, &h->tw_nlo, pl.n, nlo, 1))) return rc;
   if ((rc = upload_table(h, &h->tw_nhi, pl.n, std::max<uint64_t>(1, nhi), nlo))) return rc;
+  h->priv_grid = pl.fast_k2_priv ? 2 * std::max(1, h->lane_ncu) : 0;   // two 80-KiB workgroups per CU
   if ((rc = setup_fast(h))) return rc;
   {
     char nm[64];
@@ -1791,6 +1962,12 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
       h->kname[KID_K2] = nm;
     }
 #ifndef FRBCH_NO_FAST
+    if (pl.fast_k2_priv) {
+      snprintf(nm, sizeof nm, "frbch_k2_priv<%d>", h->cfg.pol_mode == 2 ? 2 : (h->cfg.pol_mode >= 4 ? 4 : 0));
+      h->kname[KID_K2] = nm;
+      snprintf(nm, sizeof nm, "frbch_k2_priv<%d,stats>", h->cfg.pol_mode == 2 ? 2 : (h->cfg.pol_mode >= 4 ? 4 : 0));
+      h->kname[KID_K2S] = nm;
+    }
     if (pl.fast_k2_lane) {
       snprintf(nm, sizeof nm, "frbch_k2_lane<%d,%d>", pl.fast_k2_lane, h->cfg.pol_mode == 2 ? 2 : (h->cfg.pol_mode >= 4 ? 4 : 0));
       h->kname[KID_K2] = nm;
@@ -1890,6 +2067,7 @@ extern "C" int frbch_reset(frbch_handle* h) {
   h->pow_rows = 0;
   h->fused_rows = 0;
   h->fused_valid = false;
+  h->deferred.active = false;
   h->rows_out = h->blocks_done = 0;
   h->have_vdif = false;
   h->frames_seen = h->frames_invalid = h->frame_gaps = h->frames_filled = 0;
@@ -1921,7 +2099,7 @@ extern "C" int frbch_get_rescale(frbch_handle* h, float* offset, float* scale) {
 
 extern "C" int frbch_set_rescale(frbch_handle* h, const float* offset, const float* scale) {
   if (!h || !offset || !scale) return FRBCH_E_ARG;
-  if (h->pow_rows) return fail(h, FRBCH_E_STATE, "set_rescale while an interval is being measured");
+  if (h->pow_rows || h->deferred.active) return fail(h, FRBCH_E_STATE, "set_rescale while an interval is being measured");
   DeviceGuard dg(h->device);
   { const int rc = settle_user_stream(h); if (rc) return rc; }
   CHECK_DEV(h, dev_h2d(h->offset, offset, h->pl.ncol * sizeof(float), h->stream), "upload offset");

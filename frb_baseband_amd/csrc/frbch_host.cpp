@@ -330,6 +330,16 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
     const int tt2 = two ? (pl->fast_k2_nw == 2 ? 2 : 4) : pl->fast_k2_nw * spw2;
     if (tt2 == 2) pl->spill_tile_major = 2;
   }
+  // 2C = 2048 behind that K1: the wave-private K2 (one wave per time sample, four per workgroup, two workgroups per CU; tscrunch up
+  // to its four-sample tile).  flag bit 26 keeps frbch_k2_wave (kernel-family cross-checks)
+  pl->fast_k2_priv = 0;
+  pl->k2_priv_lds = (size_t)4 * (2048 + 256) * 8 + 1024 * 8;      // = 81,920: exactly half of the CU's 160 KiB
+  if (pl->fast_k1_wave && pl->fast_k1_log2m == 3 && pl->fast_k1_kind == 0 && pl->fast_k1_g == 8 && pl->g == 8 && !pl->fast_k1_split &&
+      pl->fast_k2_wave && pl->fast_k2_log2m == 3 && pl->c2 == 2048 && !pl->coherent && !(cfg.flags & ((1u << 21) | (1u << 26))) &&
+      pl->k2_priv_lds <= lds_limit && pl->tscr <= 4 && !pl->k2_two_stage) {
+    pl->fast_k2_priv = 1;
+    pl->spill_tile_major = 2;      // (what the paired-branch K1 writes for it, whatever tile the two-wave K2 would have taken)
+  }
   // chunks of eight time samples between the M = 32 barrier kernels (2 branches per K1 workgroup: the slab layout
   // leaves K2 one 32-byte piece per 128-KB slab)
   if (pl->fast_k1_log2m == 5 && pl->fast_k2_log2m == 5 && !pl->coherent && !(cfg.flags & (1u << 21)))

@@ -54,6 +54,9 @@ struct Plan {
   int fast_k1_kind;           // M = 8 only: 0 = 8 waves x 8 branches, 1 = 4 waves x 4 branches, 2 = 8 waves x 4 branches (2 waves/seq)
   int fast_k2_nw;             // waves per wave-private K2 workgroup (2 or 4)
   int fast_k1_wave, fast_k2_wave; // 1 = wave-private variant (8 / 4 waves per workgroup), 0 = barrier variant
+  int fast_k2_priv;           // 2C = 2048 behind the paired-branch wave K1 (tile-major spill): frbch_k2_priv, one wave per time sample, no barrier
+                              // inside the transform (kernels_k2priv.inc); launches whose K1 fell back to another layout keep frbch_k2_wave
+  size_t k2_priv_lds;
   int fast_k2_lane;           // 2C = 64 / 128 (nchan 32 / 64): frbch_k2_lane, a whole across-branch sequence per lane (1) or lane pair (2); 0 = off
   int k2_two_stage;           // tscrunch beyond the wave K2's tile: K2 writes float rows of k2_stage1_tscr time samples, frbch_k2_scrunch sums k2_two_stage of them (0 = off)
   int k2_stage1_tscr;         // ... the tscrunch K2 itself runs with (2 at 2C = 8192, else its 8-sequence tile)

@@ -11,7 +11,8 @@ struct __attribute__((aligned(16))) f4 {  // 16-byte vector of floats for coales
   float v[4];
 };
 
-enum { FRBCH_OUT_FLOAT_POWER = 0, FRBCH_OUT_CODES = 1 };
+enum { FRBCH_OUT_FLOAT_POWER = 0, FRBCH_OUT_CODES = 1,
+       FRBCH_OUT_STATS = 2 };   // rescale sums only, no rows (frbch_k2_priv: first pass of the two-pass rescale)
 
 struct KParams {
   // ---- geometry -------------------------------------------------------------------------

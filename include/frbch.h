@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define FRBCH_ABI_VERSION 3
+#define FRBCH_ABI_VERSION 4
 
 /* error codes (negative); 0 = ok.  process_vdif.py:193-198 turns a non-zero digifil exit status
  * into RunError; the CLI shim maps any of these to exit status 1 with frbch_strerror on stderr. */
@@ -135,7 +135,7 @@ typedef struct frbch_timing {
     uint64_t launches;
     double total_ms;
     double algorithmic_bytes;  /* sum over launches of the DESIGN.md per-launch byte model      */
-  } k[8];
+  } k[12];                     /* nkernels of them are in use                                    */
 } frbch_timing;
 
 /* ---- configuration helpers ------------------------------------------------------------- */

@@ -6,32 +6,28 @@ from frb_baseband_amd import sigproc, synth
 from oracle import frb_oracle as o
 
 # Tolerances (stated, see DESIGN.md "Parity"):
-#  * detected power: |P - P_oracle| <= POWER_RTOL * mean TOTAL power (PP+QQ) of that channel's series (fp32 FFTs of
-#    2^17 .. 2^26 points against an fp64 oracle).  Measured maxima on MI355X (tests/test_gpu_pins.py::
-#    test_power_error_distribution, profiles/r02_power_error_distribution.jsonl): 1.3e-6 .. 5.2e-6 over the BASELINE
-#    configurations, i.e. median 2-4 / 99.9 % ~ 20 fp32 ULP of the oracle value for Stokes I; the bound is 2x the largest.
+#  * detected power: |P - P_oracle| <= power_rtol(...) * mean TOTAL power (PP+QQ) of that channel's series (fp32 FFTs of
+#    2^17 .. 2^26 points against an fp64 oracle): a regression guard from the error model of an fp32 FFT chain; the parity
+#    statement is the relation to the fp32 CPU port (tests/test_gpu_pins.py::test_power_error_distribution).
 #  * digitised codes: identical except where the oracle's pre-rounding value lies within
 #    TIE_EPS_SIGMA (in units of the rescaled sigma, i.e. TIE_EPS_SIGMA * digi_scale code units:
 #    2e-3 of an 8-bit code, 0.5 of a 16-bit code) of a rounding boundary; such samples may differ
 #    by 1 and must stay below MISMATCH_FRAC_PER_SIGMA * digi_scale of all samples (2e-4 for 8 bit).
 POWER_RTOL = 1.1e-5     # the loosest bound any configuration needs (kept for callers that do not know N)
 
-# Per-configuration bound: an fp32 FFT chain of N = 2 C R points against the fp64 oracle errs like
-# eps * sqrt(log2 N), and a sum over T scrunched samples averages the (independent) errors down by sqrt(T).  Measured
-# maxima of |P - P_oracle| / channel mean on MI355X (profiles/r02_power_error_distribution.jsonl):
-_MEASURED_POWER_ERR = {(17, 1): 3.02e-6, (22, 1): 3.87e-6, (24, 1): 5.02e-6, (26, 8): 1.33e-6}
-
-
+# Per-configuration REGRESSION GUARD (not a parity statement): an fp32 FFT chain of N = 2 C R points against the fp64 oracle
+# errs like eps * sqrt(log2 N), and a sum over T scrunched samples averages the (independent) errors down by sqrt(T); the model
+# 1.02e-6 sqrt(log2 N) / sqrt(min(T, 8)) reproduces the maxima measured on MI355X (profiles/r02_power_error_distribution.jsonl)
+# to +-25 %, the bound is twice it.  What the error MEANS is stated by tests/test_gpu_pins.py::test_power_error_distribution:
+# the HIP chain's 99.9 % point and maximum stay within 1.5 x those of the fp32 CPU port (oracle/frb_oracle.c) of the same
+# transform -- the closest thing here to the reference's fp32 CPU program (DSPSR itself is absent: parity unpinned).
 def power_rtol(nchan, freq_res, tscr=1):
-    """2 x the measured maximum of that configuration; elsewhere 2 x the model 1.02e-6 sqrt(log2 N) / sqrt(min(T, 8))
-    (which reproduces the four measured points to within +-25 %)"""
     import math
     log2n = int(round(math.log2(2 * nchan * freq_res)))
     t = min(int(tscr), 8)
-    meas = _MEASURED_POWER_ERR.get((log2n, t))
-    if meas is None:
-        meas = 1.02e-6 * math.sqrt(log2n) / math.sqrt(t)
-    return min(POWER_RTOL, 2.0 * meas)
+    return min(POWER_RTOL, 2.0 * 1.02e-6 * math.sqrt(log2n) / math.sqrt(t))
+
+
 TIE_EPS_SIGMA = 1.0e-4
 MISMATCH_FRAC_PER_SIGMA = 1.0e-5
 CODE_TIE_EPS = TIE_EPS_SIGMA * 127.5 / 6.0          # 8-bit values, kept for reference

@@ -230,13 +230,34 @@ def test_power_error_distribution(hip_lib, name, bw, nchan, secs, pol, tscr, kw)
     ulps = err / _ulp32(want)
     stats = {"case": name, "samples": int(err.size), "rel_to_channel_mean_max": float(rel),
              "ulp_median": float(np.median(ulps)), "ulp_p999": float(np.quantile(ulps, 0.999)), "ulp_max": float(ulps.max())}
+    # The same chain in fp32 on the CPU (oracle/frb_oracle.c: plain-C Stockham FFTs, the closest thing here to what the reference
+    # really launches -- digifil is an fp32 CPU program, process_vdif.py:157-161) against the same fp64 oracle.  north_star's
+    # "within 1 ULP of the digifil path" cannot be tested without DSPSR; what CAN be stated is that the HIP chain errs no more
+    # than an fp32 CPU implementation of the same transform does: 99.9 % point and maximum within 1.5 x the C port's.
+    if not kw.get("coherent"):
+        from oracle import c_oracle
+        r_ = ocfg.result["geometry"][0]
+        payload = raw[: raw.size // 8032 * 8032].reshape(-1, 8032)[:, 32:].reshape(-1)
+        cp = c_oracle.block_power(payload, nchan, r_, nblocks, pol, tscr).astype(np.float64)      # [nif][C][nt], ascending channels
+        if bw > 0:
+            cp = cp[:, ::-1, :]
+        cerr = np.abs(cp.transpose(2, 0, 1) - want)
+        c_rel = cerr / chan_scale
+        h_rel = err / chan_scale
+        stats.update({"cport_rel_max": float(c_rel.max()), "cport_rel_p999": float(np.quantile(c_rel, 0.999)),
+                      "hip_rel_p999": float(np.quantile(h_rel, 0.999)),
+                      "cport_ulp_median": float(np.median(cerr / _ulp32(want))), "cport_ulp_p999": float(np.quantile(cerr / _ulp32(want), 0.999)),
+                      "cport_ulp_max": float((cerr / _ulp32(want)).max())})
     print("POWER-ERR " + json.dumps(stats))
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/power_error_distribution.jsonl", "a") as f:
         f.write(json.dumps(stats) + "\n")
-    bound = pu.power_rtol(nchan, ocfg.result["geometry"][0], tscr)       # 2 x this configuration's own measured maximum
+    bound = pu.power_rtol(nchan, ocfg.result["geometry"][0], tscr)       # regression guard: 2 x the fp32-chain error model
     stats["bound"] = bound
     assert rel <= bound, stats
+    if "cport_rel_max" in stats:
+        assert stats["rel_to_channel_mean_max"] <= 1.5 * stats["cport_rel_max"], stats
+        assert stats["hip_rel_p999"] <= 1.5 * stats["cport_rel_p999"], stats
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -53,7 +53,7 @@ def test_unknown_flag_bits_are_rejected(emu_lib):
 
 def test_product_library_is_not_an_experiments_build(hip_lib):
     assert b"experiments" not in hip_lib.frbch_version()
-    assert b"abi 3" in hip_lib.frbch_version()
+    assert b"abi 4" in hip_lib.frbch_version()
 
 
 @pytest.mark.parametrize("bw,nchan,secs,kw", [
@@ -248,10 +248,11 @@ def test_bench_maps_profiler_kernel_names_to_timing_slots():
     assert bench.short_kernel_name("void fast::frbch_k1_wave<3, 8, 1, true, false>(KParams)") in bench.VALU_PER_WAVE_BLOCK
 
 
-def test_bench_dominant_kernel_rule_with_and_without_overlap():
-    """bench.py: kernels one after the other -> the dominant kernel is the one with the largest summed launch time; when the
-    per-kernel times add up to more than the step (K1 beside the previous IF's digitiser), K1 and the digitiser are priced together
-    (`overlapped_pair`) and the dominant kernel is the one with the most time of the chip to itself"""
+def test_bench_roofline_follows_survey_8d():
+    """bench.py: `roofline.frac` is the whole path priced with the SURVEY 8(d) budget (18.5 B per sample for four 8-bit products),
+    the dominant kernel is the one with the largest summed launch time WITHOUT exclusions, priced with its share of that budget
+    (K1 0.502 + 8, K2 8 + output codes, digitiser / statistics / K0 nothing); the engine's own byte model (float rows of a
+    buffered interval included) stays apart"""
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
@@ -259,24 +260,28 @@ def test_bench_dominant_kernel_rule_with_and_without_overlap():
         import bench
     finally:
         sys.path.remove(root)
+    spec = dict(nif=8, bw=32.0, nchan=1024, pol=5, tscrunch=1, seconds=10.0, coherent=False)
+    assert abs(bench.budget_bytes_per_sample(spec) - 18.502) < 1e-9
+    assert abs(bench.budget_bytes_per_sample(dict(spec, pol=2)) - 17.002) < 1e-9
+    assert abs(bench.budget_bytes_per_sample(dict(spec, pol=2, coherent=True)) - 33.002) < 1e-9
+    share = bench.budget_share_bytes_per_sample
+    assert share("frbch_k1_wave<3,8,1>", spec) == 8.502 and share("frbch_k2_priv<5>", spec) == 10.0
+    assert share("frbch_k2_priv<5,stats>", spec) == 10.0            # (a second pass over the spill is priced like the first: no extra credit)
+    assert share("frbch_quantise_fast<8>", spec) == 0.0 and share("frbch_k0_stage", spec) == 0.0 and share("frbch_stats", spec) == 0.0
+    # the shares of the kernels of one pass add up to the budget
+    assert abs(share("frbch_k1_wave<3,8,1>", spec) + share("frbch_k2_wave<3,4,4,2>", spec) - bench.budget_bytes_per_sample(spec)) < 1e-9
+    coh = dict(spec, pol=2, coherent=True)
+    assert abs(sum(share(k, coh) for k in ("frbch_k1_wave<4,8,2>", "frbch_k2c_fast", "frbch_k3_wave<4>", "frbch_k4_fast")) -
+               bench.budget_bytes_per_sample(coh)) < 1e-9
     rec = lambda ms, gb: {"launches": 8, "total_ms": ms, "algorithmic_bytes": gb * 1e9}
-    serial = {"frbch_k1_wave<3,8,1>": rec(12.4, 43.4), "frbch_k2_wave<3,4,4,2>": rec(15.0, 81.6), "frbch_quantise_fast<8>": rec(9.4, 51.0),
+    samples = 5.1e9
+    timing = {"frbch_k1_wave<3,8,1>": rec(18.2, 43.4), "frbch_k2_wave<3,4,4,2>": rec(15.0, 81.6), "frbch_quantise_fast<8>": rec(18.6, 51.0),
               "frbch_k0_stage": rec(0.9, 5.1)}
-    dt = 0.0385     # 38.5 ms: the kernels add up to 37.7
-    assert not bench.kernels_overlap(serial, 1, dt)
-    name, r, ach = bench.roofline_of(serial, 1, dt)
-    assert name == "frbch_k2_wave<3,4,4,2>" and abs(ach - 81.6 / 15.0e-3) < 1e-6
-    assert bench.overlapped_pair(serial, 1, dt) is None
-    shared = dict(serial)
-    shared["frbch_k1_wave<3,8,1>"] = rec(18.2, 43.4)
-    shared["frbch_quantise_fast<8>"] = rec(18.0, 51.0)
-    dt = 0.0363     # 36.3 ms per step although the kernels add up to 52
-    assert bench.kernels_overlap(shared, 1, dt)
-    name, r, ach = bench.roofline_of(shared, 1, dt)
-    assert name == "frbch_k2_wave<3,4,4,2>"
-    pair = bench.overlapped_pair(shared, 1, dt)
-    assert pair["kernels"] == ["frbch_k1_wave<3,8,1>", "frbch_quantise_fast<8>"]
-    assert abs(pair["achieved"] - (43.4 + 51.0) / 18.2e-3) < 0.1 and 0 < pair["frac"] < 1
-    assert "side by side" in bench.concurrency_note(shared, 1, dt) or "beside" in bench.concurrency_note(shared, 1, dt)
-    # without the step time the plain rule applies
-    assert bench.roofline_of(shared, 1)[0] == "frbch_k1_wave<3,8,1>"
+    name, r, ach, model = bench.roofline_of(timing, spec, samples)
+    assert name == "frbch_quantise_fast<8>" and ach == 0.0 and abs(model - 51.0 / 18.6e-3) < 1e-6      # no exclusions: the digitiser, worth nothing
+    del timing["frbch_quantise_fast<8>"]
+    name, r, ach, model = bench.roofline_of(timing, spec, samples)
+    assert name == "frbch_k1_wave<3,8,1>" and abs(ach - 8.502 * samples / 18.2e-3 / 1e9) < 1e-6
+    assert bench.kernels_overlap(timing, 1, 0.030) and not bench.kernels_overlap(timing, 1, 0.0385)
+    total, missing = bench.step_traffic({"frbch_k1_wave<3,8,1>": 5.4e9, "frbch_k0_stage": 0.6e9}, timing, 1)
+    assert abs(total - 8 * 6.0e9) < 1 and missing == ["frbch_k2_wave<3,4,4,2>"]
