@@ -183,12 +183,22 @@ struct DeviceGuard {
   DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
 
-// kernel-selection switches a product build accepts (include/frbch.h); everything else is an experiment
-constexpr uint32_t kProductFlags = 1u | 2u | 4u | 8u | 16u | 32u | 64u | 128u | (1u << 20) | (1u << 21) | (1u << 22) | (1u << 23) | (1u << 24) | (1u << 25) | (1u << 26) | (1u << 27);
+// cfg.flags of a product build (include/frbch.h): four kernel-selection switches, every one produces the same (correct) output
+// and has parity cases.  Everything else -- rejected kernel variants, layouts and lane modes kept for A/B runs, the timing-only
+// ablations of bits 8..19 -- exists only in libraries built with -DFRBCH_EXPERIMENTS; bit 22 (whole-file paths without their
+// reader / writer threads) also in the test-only emulator build.
+constexpr uint32_t kFlagGenericK1 = 1u, kFlagGenericK2 = 2u, kFlagSeparateStats = 1u << 20, kFlagTwoPass = 1u << 27;
+constexpr uint32_t kProductFlags = kFlagGenericK1 | kFlagGenericK2 | kFlagSeparateStats | kFlagTwoPass;
 constexpr uint32_t kFlagNoPipeline = 1u << 22, kFlagNoK0 = 1u << 23, kFlagGenericQuant = 1u << 25;
+[[maybe_unused]] constexpr uint32_t kExperimentFlags = 4u | 8u | 16u | 32u | 64u | 128u | (1u << 21) | (1u << 22) | (1u << 23) | (1u << 24) | (1u << 25) | (1u << 26);
 #ifdef FRBCH_EXPERIMENTS
-constexpr uint32_t kAcceptedFlags = kProductFlags | 0x000FFF00u;
+constexpr bool kExperiments = true;
+constexpr uint32_t kAcceptedFlags = kProductFlags | kExperimentFlags | 0x000FFF00u;
+#elif defined(FRBCH_TEST_HOOKS)
+constexpr bool kExperiments = false;
+constexpr uint32_t kAcceptedFlags = kProductFlags | kFlagNoPipeline;
 #else
+constexpr bool kExperiments = false;
 constexpr uint32_t kAcceptedFlags = kProductFlags;
 #endif
 
@@ -373,10 +383,13 @@ void launch_k1_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s, i
     } else
     FRBCH_K1W(4, 8, 2, 512);
   } else {
+#ifdef FRBCH_EXPERIMENTS   // K1 shapes with more, smaller waves (flags 64 / 128): all measured slower than eight wave-private waves
     if (LOG2M == 3 && pl.fast_k1_kind == 1) FRBCH_K1W(3, 4, 1, 256);
     else if (LOG2M == 3 && pl.fast_k1_kind == 2) FRBCH_K1W(3, 8, 2, 512);
     else if (LOG2M == 3 && pl.fast_k1_kind == 3) FRBCH_K1W(3, 16, 2, 1024);
-    else FRBCH_K1W(LOG2M, 8, 1, 512);
+    else
+#endif
+    FRBCH_K1W(LOG2M, 8, 1, 512);
   }
 #undef FRBCH_K1W
   if (stamp_path && nb > 8 * ny) {
@@ -488,10 +501,12 @@ void launch_k2_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s, u
       else if (pm == 4) hipLaunchKernelGGL((fast::frbch_k2_wave<3, 8, 4, 2>), grid4, dim3(512), pl.k2_fast_lds, s, p);
       else hipLaunchKernelGGL((fast::frbch_k2_wave<3, 8, 0, 2>), grid4, dim3(512), pl.k2_fast_lds, s, p);
     }
-  } else if (pl.fast_k2_nw == 2) {
+  } else if constexpr (LOG2M != 3 || kExperiments) {   // (2C = 2048 with one wave per sequence and 2 / 4 waves: flag 32, experiments builds only)
+  if (pl.fast_k2_nw == 2) {
     if (pm == 2) FRBCH_K2W(2, 2, grid2); else if (pm == 4) FRBCH_K2W(2, 4, grid2); else FRBCH_K2W(2, 0, grid2);
   } else {
     if (pm == 2) FRBCH_K2W(4, 2, grid4); else if (pm == 4) FRBCH_K2W(4, 4, grid4); else FRBCH_K2W(4, 0, grid4);
+  }
   }
   }
 #undef FRBCH_K2W
@@ -589,6 +604,7 @@ bool launch_k1_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
     if (h->stg_ready) q.stg = h->stg_cur ? h->stg_cur : h->stg;   // launch_k0_stage has corner-turned this batch
     h->stg_ready = false;
     q.tile_major = p.tile_major = pl.spill_tile_major;   // 2 (R = 2048, paired branches) or 8 (R = 8192) or 0 (K2 of this batch reads what this launch writes)
+#ifdef FRBCH_EXPERIMENTS
     if (pl.fast_k1_split && q.stg) {    // persistent over blocks, one 16-wave workgroup per CU
       q.nblk = nb;
       const uint32_t ngrp = (uint32_t)(pl.c2 / 8);
@@ -598,6 +614,7 @@ bool launch_k1_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
       return true;
     }
     if (pl.fast_k1_split) h->kname[KID_K1] = "frbch_k1_wave<3,8,1>";
+#endif
     switch (pl.fast_k1_log2m) {
       case 1: launch_k1_wave_t<1>(pl, q, nb, s, h->lane_cus); break;
       case 2: launch_k1_wave_t<2>(pl, q, nb, s, h->lane_cus); break;
@@ -716,10 +733,12 @@ bool launch_k2_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
     return true;
   }
   switch (pl.fast_k2_log2m) {
+#ifdef FRBCH_EXPERIMENTS   // the barrier K2 below 2C = 8192: flags 4 / 8 only
     case 1: launch_k2_fast_t<1>(pl, p, nb, s); break;
     case 2: launch_k2_fast_t<2>(pl, p, nb, s); break;
     case 3: launch_k2_fast_t<3>(pl, p, nb, s); break;
     case 4: launch_k2_fast_t<4>(pl, p, nb, s); break;
+#endif
     case 5:
       if (pl.fast_k2_nt == 512) hipLaunchKernelGGL((fast::frbch_k2_fast<5, 512>), dim3(pl.r, nb), dim3(512), pl.k2_fast_lds, s, p);   // one time sample per workgroup (tscrunch 1)
       else hipLaunchKernelGGL((fast::frbch_k2_fast<5, 1024>), dim3(pl.r / std::max(2, pl.tscr), nb), dim3(1024), pl.k2_fast_lds, s, p);
@@ -756,8 +775,12 @@ bool launch_k3_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
       hipLaunchKernelGGL((fast::frbch_k3_wave<4>), dim3((unsigned)std::min<uint64_t>(ntiles, kK3WaveWgs)), dim3(256), pl.k3_fast_lds, s, p);
       return true;
     }
+#ifdef FRBCH_EXPERIMENTS
     hipLaunchKernelGGL((fast::frbch_k3_fast<4, 512>), grid, dim3(512), pl.k3_fast_lds, s, p);
     return true;
+#else
+    return false;
+#endif
   }
   switch (pl.coh_fast_r) {
     case 1: hipLaunchKernelGGL((fast::frbch_k3_fast<1, 1024>), grid, dim3(1024), pl.k3_fast_lds, s, p); break;
@@ -819,12 +842,14 @@ int setup_fast(frbch_handle* h) {
       }
     }
     if ((rc = upload_cf(h, &h->td1, d1)) || (rc = upload_cf(h, &h->td2, d2))) return rc;
+#ifdef FRBCH_EXPERIMENTS
     if (pl.fast_k1_split) {
       std::vector<float> h1, h2;
       fft_tables(pl.r / 2, &h1, &h2);
       if ((rc = upload_cf(h, &h->ftw1_h, h1)) || (rc = upload_cf(h, &h->ftw2_h, h2))) return rc;
       if ((rc = allow_lds(h, fast::frbch_k1_split, pl.k1_split_lds))) return rc;
     }
+#endif
     if (!h->stg)
       CHECK_DEV(h, dev_malloc((void**)&h->stg, (size_t)pl.maxb * pl.block_payload_bytes), "hipMalloc(staged payload)");
 #define FRBCH_AL(L, NWV, WPSV) do { if (!rc) rc = allow_lds(h, fast::frbch_k1_wave<L, NWV, WPSV, false>, pl.k1_fast_lds); \
@@ -839,7 +864,11 @@ int setup_fast(frbch_handle* h) {
         if (!rc) rc = allow_lds(h, fast::frbch_k1_wave<4, 8, 2, true, true>, pl.k1_fast_lds);
         break;
       case 5: FRBCH_AL(5, 8, 4); break;
+#ifdef FRBCH_EXPERIMENTS
       default: FRBCH_AL(3, 8, 1); FRBCH_AL(3, 4, 1); FRBCH_AL(3, 8, 2); FRBCH_AL(3, 16, 2); break;
+#else
+      default: FRBCH_AL(3, 8, 1); break;
+#endif
     }
 #undef FRBCH_AL
     else switch (pl.fast_k1_log2m) {
@@ -869,7 +898,11 @@ int setup_fast(frbch_handle* h) {
       case 2: rc = allow_lds(h, fast::frbch_k3_fast<2, 1024>, pl.k3_fast_lds); break;
       case 3: rc = allow_lds(h, fast::frbch_k3_fast<3, 1024>, pl.k3_fast_lds); break;
       case 4:
+#ifdef FRBCH_EXPERIMENTS
         rc = pl.coh_nt == 512 ? allow_lds(h, fast::frbch_k3_fast<4, 512>, pl.k3_fast_lds) : allow_lds(h, fast::frbch_k3_fast<4, 1024>, pl.k3_fast_lds);
+#else
+        rc = pl.coh_nt == 512 ? FRBCH_OK : allow_lds(h, fast::frbch_k3_fast<4, 1024>, pl.k3_fast_lds);
+#endif
         if (!rc && pl.coh_nt == 512) rc = allow_lds(h, fast::frbch_k3_wave<4>, pl.k3_fast_lds);
         break;
       default: rc = allow_lds(h, fast::frbch_k3_fast<5, 1024>, pl.k3_fast_lds); break;
@@ -929,7 +962,8 @@ int setup_fast(frbch_handle* h) {
       if (pl.fast_k2_log2m == 1) { FRBCH_ALLOW_L(1); }
       else if (pl.fast_k2_log2m == 2) { FRBCH_ALLOW_L(2); }
       else {
-        FRBCH_ALLOW_L(3);
+        if constexpr (kExperiments) { FRBCH_ALLOW_L(3); }
+        else { FRBCH_ALLOW(3, 8, 0); FRBCH_ALLOW(3, 8, 2); FRBCH_ALLOW(3, 8, 4); }
         if (!rc) rc = allow_lds(h, fast::frbch_k2_wave<3, 4, 0, 2>, pl.k2_fast_lds);
         if (!rc) rc = allow_lds(h, fast::frbch_k2_wave<3, 4, 2, 2>, pl.k2_fast_lds);
         if (!rc) rc = allow_lds(h, fast::frbch_k2_wave<3, 4, 4, 2>, pl.k2_fast_lds);
@@ -943,10 +977,14 @@ int setup_fast(frbch_handle* h) {
 #undef FRBCH_ALLOW
     }
     else switch (pl.fast_k2_log2m) {
+#ifdef FRBCH_EXPERIMENTS
       case 1: rc = big ? allow_lds(h, fast::frbch_k2_fast<1, 1024>, pl.k2_fast_lds) : allow_lds(h, fast::frbch_k2_fast<1, 512>, pl.k2_fast_lds); break;
       case 2: rc = big ? allow_lds(h, fast::frbch_k2_fast<2, 1024>, pl.k2_fast_lds) : allow_lds(h, fast::frbch_k2_fast<2, 512>, pl.k2_fast_lds); break;
       case 3: rc = big ? allow_lds(h, fast::frbch_k2_fast<3, 1024>, pl.k2_fast_lds) : allow_lds(h, fast::frbch_k2_fast<3, 512>, pl.k2_fast_lds); break;
       case 4: rc = big ? allow_lds(h, fast::frbch_k2_fast<4, 1024>, pl.k2_fast_lds) : allow_lds(h, fast::frbch_k2_fast<4, 512>, pl.k2_fast_lds); break;
+#else
+      case 1: case 2: case 3: case 4: rc = fail(h, FRBCH_E_ARG, "the barrier K2 below 8192 branches exists only in experiments builds"); break;
+#endif
       default: rc = big ? allow_lds(h, fast::frbch_k2_fast<5, 1024>, pl.k2_fast_lds) : allow_lds(h, fast::frbch_k2_fast<5, 512>, pl.k2_fast_lds); break;
     }
     if (rc) return rc;
@@ -1419,6 +1457,9 @@ Lanes* get_lanes(int device, int ncu_front, bool plain = false) {
     ln->ok = true;
     return ln;
   }
+#ifndef FRBCH_EXPERIMENTS
+  return nullptr;   // CU-masked lanes (overlap modes 1 and 2) were measured slower: experiments builds only
+#else
   if (ln->ncu < 32 || ln->ncu % 8 || ncu_front < 8 || ncu_front > ln->ncu - 8 || ncu_front % 8) return nullptr;
   const uint32_t words = (uint32_t)((ln->ncu + 31) / 32);
   std::vector<uint32_t> mf(words, 0u), mb(words, 0u);
@@ -1435,6 +1476,7 @@ Lanes* get_lanes(int device, int ncu_front, bool plain = false) {
   ln->ncu_f = ncu_front;
   ln->ok = true;
   return ln;
+#endif
 }
 
 dev_event_t pool_event(frbch_handle* h) {
@@ -1912,7 +1954,12 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
   if (ndev <= 0) return fail(h, FRBCH_E_DEVICE, "no GPU visible to HIP (there is no CPU fallback)");
   if (cfg->device >= ndev) return fail(h, FRBCH_E_DEVICE, "device ordinal out of range");
   if (cfg->flags & ~kAcceptedFlags)
-    return fail(h, FRBCH_E_ARG, "unknown bit in cfg.flags (timing-only ablations exist only in FRBCH_EXPERIMENTS builds)");
+    return fail(h, FRBCH_E_ARG, "unknown bit in cfg.flags (kernel variants kept for A/B runs and timing-only ablations exist only in FRBCH_EXPERIMENTS builds)");
+  if (!kExperiments) {   // overlap: automatic (0), off (1), or the plain-stream mode 3 with a CU count; no CU-masked lanes, no forced batching
+    const uint32_t mode = (cfg->overlap >> 24) & 0xFFu, batches = (cfg->overlap >> 16) & 0xFFu;
+    if ((mode != 0 && mode != 3) || batches)
+      return fail(h, FRBCH_E_ARG, "cfg.overlap: CU-masked lane modes and forced batching exist only in FRBCH_EXPERIMENTS builds");
+  }
   h->device = cfg->device;
   DeviceGuard dg(h->device);
   char arch[128] = "";

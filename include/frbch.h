@@ -60,18 +60,13 @@ typedef struct frbch_config {
   uint32_t coherent;           /* -F<nchan>:D (process_vdif.py:179-180): dedisperse in the filterbank */
   int32_t device;              /* GPU ordinal (>= 0)                                          */
   uint32_t max_blocks_per_launch; /* 0 = auto; filterbank blocks batched per kernel launch    */
-  uint32_t flags;              /* 0 in production.  Kernel-selection switches, every one produces the same (correct) output and
-                                * has parity cases: 1 generic K1, 2 generic K2, 4 1024-thread K2, 8 barrier (non wave-private)
-                                * kernels, 16 4-sequence K2, 32 one wave per sequence in K2, 64/128 alternative K1 shapes,
-                                * 1<<20 rescale statistics in a separate pass over the power buffer instead of inside K2,
-                                * 1<<21 slab layout of the spill where the tile-major one would be used, 1<<22 whole-file paths
-                                * without reader / writer threads, 1<<23 K1 gathers from the frames (no corner-turned copy),
-                                * 1<<24 frbch_k1_split (R = 2048: bin-parity halves, 16 independent waves per CU; measured 14 %
-                                * slower than the default wave K1, kept as a parity-tested alternative),
-                                * 1<<25 the generic digitiser (frbch_quantise) for a buffered rescale interval where the lean
-                                * 8-bit stream (frbch_quantise_fast) would run.
-                                * Any other bit makes frbch_open fail with FRBCH_E_ARG: bits 8..19 (timing-only ablations that
-                                * produce WRONG output) and the environment knobs of the profiling notes exist only in
+  uint32_t flags;              /* 0 in production.  Four kernel-selection switches, every one produces the same (correct) output and
+                                * has parity cases: 1 generic (radix-2) K1, 2 generic K2 and back end -- the cross-check family of
+                                * tests/test_gpu_stress.py --, 1<<20 rescale statistics in a separate pass over the buffered power
+                                * rows instead of inside K2, 1<<27 two-pass rescale of a first `-c` interval (K2 runs twice over the
+                                * resident spill instead of buffering float rows; measured slower).
+                                * Any other bit makes frbch_open fail with FRBCH_E_ARG: rejected kernel variants, layouts and lane
+                                * modes kept for A/B runs and the timing-only ablations (which produce WRONG output) exist only in
                                 * libraries built with -DFRBCH_EXPERIMENTS (make EXPERIMENTS=1), never in the product build. */
   char telescope[64];          /* .hdr TELESCOPE  (process_vdif.py:123)                       */
   char source[64];             /* .hdr SOURCE     (:124)                                      */
@@ -80,16 +75,12 @@ typedef struct frbch_config {
   char datafile[512];          /* .hdr DATAFILE   (:129)                                      */
   uint32_t input_bits;         /* bits per sample of the VDIF: 2, or 1 (mode VDIF_8000-1024-16-1, spif2file.sh:58-61);
                                 * 0 = take it from the first frame header (host paths) / 2 (device paths)            */
-  uint32_t overlap;            /* 0 in production (automatic).  Two kernels of a scan share the device.
-                                * Bits 0..15: compute units left to the front kernels (K0, K1, Kc; multiple of 8; 1 = no overlap:
-                                * every kernel on the whole chip, one after the other).  Bits 24..25, what runs beside them:
-                                * 3 (automatic choice) = the digitiser of a completed rescale interval beside the K1 of the next IF
-                                * of a scan, on plain streams -- it holds the other CUs by an LDS reservation (automatic: four
-                                * products at 8 bits, 11/16 of the CUs for K1; else off); 2 = the same on streams with complementary
-                                * CU masks (measured slower: a masked queue delays every launch); 1 = K2, statistics and digitiser
-                                * on a masked back lane beside the K1 of the next batch (measured slower: both kernels scale with
-                                * their share of the CUs), with bits 16..23 = batches a call is cut into.  Every setting produces
-                                * the same output.                                                                              */
+  uint32_t overlap;            /* 0 in production (automatic).  The digitiser of a completed rescale interval may run beside the K1 of
+                                * the next IF of a scan, on plain streams, holding its CUs by an LDS reservation (DESIGN.md section
+                                * 4b; automatic: four products at 8 bits, 11/16 of the CUs for K1; else off).  1 = off: every kernel
+                                * on the whole chip, one after the other.  (3 << 24) | n = that mode with n CUs (a multiple of 8)
+                                * left to K1.  Every setting produces the same output.  CU-masked lane modes (1 << 24, 2 << 24) and
+                                * forced batching (bits 16..23) were measured slower and exist only in FRBCH_EXPERIMENTS builds. */
   float levels[4];             /* 2-bit level table, state 0..3 -> voltage (process_vdif.py:157 passes the bare `-2`: DSPSR's
                                 * static table); all four 0 = the default -3.3359, -1, +1, +3.3359.  A run-time table in
                                 * every kernel, so another level scheme is a data change.                                  */

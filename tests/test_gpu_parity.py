@@ -23,28 +23,16 @@ CASES = [
     (16.0, 32, 0.05, dict(pol=1, freq_res=64, interval=0.004, const=0)),  # no -c: per-interval rescale
     (16.0, 32, 0.05, dict(freq_res=64, interval=0.004, const=1, maxb=3)),
     (32.0, 1024, 0.14, {}),                                  # BASELINE config 2 shape, 2 blocks (fast K1+K2, M=8)
-    (32.0, 1024, 0.14, dict(flags=1 << 24)),                 # frbch_k1_split (bin-parity halves, 16 waves per CU) instead of the wave K1
-    (-32.0, 1024, 0.14, dict(flags=(1 << 24) | (1 << 21), pol=4)),   # ... storing the slab layout
-    (32.0, 1024, 0.27, dict(flags=1 << 24, maxb=3)),         # ... over uneven batches (3 + 1 blocks)
     (32.0, 1024, 0.27, dict(maxb=3)),
-    (32.0, 1024, 0.14, dict(flags=1 << 23)),                 # no corner-turned copy: the wave K1 gathers from the frames
-    (32.0, 1024, 0.14, dict(flags=1 << 21)),                 # slab layout of the spill instead of the tile-major one
-    (-32.0, 1024, 0.14, dict(flags=1 << 21, pol=4, tscr=2)),
     (32.0, 1024, 0.14, dict(flags=3)),                       # same through the generic kernels
     (32.0, 1024, 0.14, dict(flags=1)),                       # generic K1 + fast K2
     (32.0, 1024, 0.14, dict(flags=2)),                       # fast K1 + generic K2
-    (32.0, 1024, 0.14, dict(flags=4)),                       # 1024-thread K2
-    (32.0, 1024, 0.14, dict(flags=32)),                      # one wave per sequence in K2
-    (-32.0, 1024, 0.14, dict(flags=32, pol=4, tscr=4)),
-    (32.0, 1024, 0.14, dict(flags=16, pol=4)),               # 4 sequences per K2 workgroup
-    (32.0, 1024, 0.14, dict(flags=64)),                      # K1 variants: 8 waves x 4 branches, two waves per sequence
-    (32.0, 1024, 0.14, dict(flags=128)),                     # 16 waves x 8 branches, two waves per sequence
-    (-32.0, 1024, 0.14, dict(flags=192, pol=4)),             # 4 waves x 4 branches
-    (32.0, 1024, 0.14, dict(flags=8)),                       # barrier variants of the fast kernels
-    (-32.0, 1024, 0.14, dict(flags=8, pol=4, tscr=4)),
-    (16.0, 256, 0.04, dict(flags=8, pol=4, tscr=8)),
-    (-16.0, 512, 0.08, dict(flags=8, tscr=2)),
     (-32.0, 1024, 0.14, dict(pol=4, tscr=2)),                # BASELINE config 3 shape (-d4), LSB, -t 2
+    # two-pass rescale of a first interval (flag 1 << 27): frbch_k2_priv sums only, then digitises the same resident spill
+    (32.0, 1024, 0.14, dict(flags=1 << 27)),                 # the scan ends inside its first interval: second pass at the flush
+    (-32.0, 1024, 0.27, dict(flags=1 << 27, pol=5, interval=0.1)),       # the interval ends inside the (only) batch: statistics over its rows, codes for all
+    (32.0, 1024, 0.27, dict(flags=1 << 27, pol=4, tscr=2, nbit=16, maxb=3)),   # a second batch arrives while the first is deferred: its float rows are written after all
+    (32.0, 1024, 0.27, dict(flags=1 << 27, pol=2, tscr=4, nbit=2, interval=0.1, maxb=2)),   # interval end inside the second batch: buffered form
     (-32.0, 1024, 0.14, dict(pol=4, tscr=4, nbit=-32)),
     (32.0, 1024, 0.14, dict(pol=0, nbit=2, tscr=4)),
     (32.0, 1024, 0.14, dict(tscr=8)),                        # -t 8: 8-sequence K2 workgroups
@@ -76,7 +64,6 @@ CASES = [
     (-32.0, 512, 0.15, dict(dm=26.7, coherent=1, freq=350.0, pol=4, tscr=2, nbit=16)),
     (32.0, 2048, 0.6, dict(dm=56.7, coherent=1, freq=1400.0, freq_res=4096)),   # BASELINE config 5 shape: -F2048:4096 -D 56.7 -F2048:D (register-pass K1 / K2c / K3, M = 16)
     (32.0, 2048, 0.6, dict(dm=56.7, coherent=1, freq=1400.0, freq_res=4096, flags=3)),   # the same on the generic kernels
-    (32.0, 2048, 0.6, dict(dm=56.7, coherent=1, freq=1400.0, freq_res=4096, flags=8)),   # the same with the barrier K1 (frbch_k1_fast<4>) instead of the forward-only wave K1
     (-32.0, 2048, 0.6, dict(dm=56.7, coherent=1, freq=1400.0, freq_res=4096, pol=5, tscr=2, nbit=16)),   # wave K1 / K3 at R = 4096: four products (IQUV), -t 2, LSB, sums fused in K3
     (32.0, 2048, 0.6, dict(dm=30.0, coherent=1, freq=1400.0, freq_res=4096, pol=0, tscr=4, nbit=2, interval=0.2)),   # ... one product, -t 4, 2-bit codes, the rescale interval ends inside the scan
     (-32.0, 1024, 0.3, dict(dm=56.7, coherent=1, freq=400.0, tscr=4, flags=1)),  # generic K1 / K3 (bit-reversed bins) + register-pass K2c
@@ -85,14 +72,11 @@ CASES = [
     (16.0, 256, 0.2, dict(dm=20.0, coherent=1, freq=600.0, pol=0, nbit=16)),     # M = 2 / 2
     (64.0, 4096, 1.1, dict(tscr=8)),                         # BASELINE config 4 shape (-t 8 -F4096:8192), 2 blocks: M = 32 wave kernels, two-stage tscrunch (K2 rows of two samples + frbch_k2_scrunch)
     (-64.0, 4096, 0.55, dict(tscr=4, nbit=2)),                # two-stage tscrunch, factor 2, 2-bit codes, LSB
-    (64.0, 4096, 0.55, dict(tscr=8, flags=8)),                # the barrier kernels: K2 (frbch_k2_fast<5,1024>) walks 4 sub-tiles
     (64.0, 4096, 0.55, dict(tscr=8, flags=3)),                # the same through the generic kernels
     (-64.0, 4096, 0.55, {}),                                  # M = 32, -t 1, LSB: wave K2 (frbch_k2_wave<5,8,2,4>, two time samples per workgroup, sums fused)
     (64.0, 4096, 0.55, dict(tscr=2, nbit=-32)),               # the same with -t 2 (one output row per tile)
     (64.0, 4096, 1.1, dict(pol=1, nbit=16)),                  # the same kernel family, single-product instantiation, 2 blocks, USB
     (64.0, 4096, 0.55, dict(flags=1 << 20, nbit=2)),          # wave K2 with the separate statistics pass
-    (64.0, 4096, 0.55, dict(flags=8)),                        # -t 1 on the barrier K2 (frbch_k2_fast<5,512>)
-    (64.0, 4096, 0.55, dict(flags=1 << 21, tscr=2)),          # M = 32 with the slab layout of the spill instead of chunks of eight time samples
     (64.0, 4096, 0.55, dict(pol=4, tscr=2, nbit=16)),         # M = 32, coherency products
     (64.0, 4096, 0.55, dict(pol=4, tscr=4)),                  # four products and tscrunch > 2: barrier K2 (two-sample rows) + frbch_k2_scrunch (round 3; generic K2 before)
     (-64.0, 4096, 0.55, dict(pol=5, tscr=8, nbit=16)),        # ... the IQUV spelling of config 4's `-t 8`
@@ -100,7 +84,6 @@ CASES = [
     # Stokes I,Q,U,V (pol_mode 5, the `-d4 -iquv` extension; north_star "IQUV formation") through every K2 family
     (32.0, 1024, 0.14, dict(pol=5)),                         # wave K2, MSTAT instantiation while the interval is measured
     (-32.0, 1024, 0.14, dict(pol=5, tscr=2, nbit=16)),
-    (32.0, 1024, 0.14, dict(pol=5, flags=8, tscr=4)),        # barrier K2
     (32.0, 1024, 0.14, dict(pol=5, flags=2)),                # generic K2
     (16.0, 128, 0.05, dict(pol=5, tscr=8, nbit=-32)),        # 2C = 256 wave K2
     (64.0, 4096, 0.55, dict(pol=5, tscr=2)),                  # M = 32

@@ -55,7 +55,8 @@ def _unpack_codes(buf, nbit, shape):
     (32.0, 1024, 0.27, 2, 8, 1, 3),            # generic kernels
     (32.0, 1024, 0.2, 2, 8, 16, 0),            # frbch_quantise_fast: fewer rows (384) than row phases: only its checked tail runs
     (32.0, 1024, 0.6, 5, 8, 1, 0),             # ... 9 blocks: an even number of pipelined trips + left-over steps
-    (-32.0, 1024, 0.27, 4, 8, 1, 1 << 25),     # the generic digitiser where the lean one would run
+    (32.0, 1024, 0.27, 5, 8, 1, 1 << 27),      # two-pass rescale: both passes of frbch_k2_priv compute the same floats
+    (-32.0, 1024, 0.27, 2, 8, 2, 1 << 27),
 ])
 def test_rescale_and_digitiser_are_bit_exact_on_the_hip_floats(hip_lib, bw, nchan, secs, pol, nbit, tscr, flags):
     raw = synth.make_vdif(secs, bw_mhz=abs(bw), nchan=nchan)
@@ -177,7 +178,7 @@ def test_custom_level_table_through_the_whole_path(hip_lib):
     """the level table is data in every kernel family (SURVEY 7 hard part 2): same oracle comparison with another table"""
     lv = (-2.75, -0.5, 0.25, 4.5)
     pu.run_streaming_case(hip_lib, 32.0, 1024, 0.14, levels=lv)                      # wave K1 (nibble table)
-    pu.run_streaming_case(hip_lib, 32.0, 1024, 0.14, levels=lv, flags=8)             # barrier K1 (select chain)
+    pu.run_streaming_case(hip_lib, -32.0, 1024, 0.3, levels=lv, dm=56.7, coherent=1, freq=400.0, tscr=4)   # barrier K1 of the coherent path (select chain)
     pu.run_streaming_case(hip_lib, -16.0, 128, 0.05, levels=lv, flags=1, pol=4)      # generic K1
 
 
@@ -496,15 +497,12 @@ def test_scan_device_config3_as_stated_against_the_oracle(hip_lib):
 
 
 @pytest.mark.parametrize("overlap,kw", [
-    (160 | (2 << 16) | (1 << 24), dict(pol=2, maxb=2)),                        # K2 on the back lane, two batches per IF
-    (128 | (3 << 16) | (1 << 24), dict(pol=5, interval=0.1, maxb=2)),          # ... four products, the interval ends inside the scan
-    (192 | (2 << 24), dict(pol=5)),                                            # the digitiser beside the next IF's K1
-    (192 | (2 << 24), dict(pol=2, interval=0.1, const=0, nbit=16, maxb=2)),    # ... an interval per 0.1 s (the power buffer is re-used)
-    (192 | (3 << 24), dict(pol=5)),                                            # ... on plain streams, its CUs held by an LDS reservation
-    (160 | (3 << 24), dict(pol=2, interval=0.1, const=0, maxb=2)),
+    (192 | (3 << 24), dict(pol=5)),                                            # the digitiser beside the next IF's K1, its CUs held by an LDS reservation
+    (160 | (3 << 24), dict(pol=2, interval=0.1, const=0, maxb=2)),             # ... an interval per 0.1 s (the power buffer is re-used)
+    (0, dict(pol=5, interval=0.1, maxb=2)),                                    # the automatic setting, the interval ends inside the scan
 ])
 def test_scan_device_lanes_give_the_same_rows(hip_lib, overlap, kw):
-    """the CU-masked lanes change WHERE and WHEN kernels run, never what they write: rows identical to the run without
+    """two kernels sharing the chip changes WHERE and WHEN kernels run, never what they write: rows identical to the run without
     overlap (frbch_config.overlap = 1), bit for bit"""
     _r, _o, plain, rows = _scan_device(hip_lib, 3, 32.0, 1024, 0.27, overlap=1, **kw)
     _r, _o, lanes, rows2 = _scan_device(hip_lib, 3, 32.0, 1024, 0.27, overlap=overlap, **kw)

@@ -135,9 +135,7 @@ def test_direct_scan_rejects_mixed_geometry(emu_lib, tmp_path):
     dict(nchan=32, freq_res=64, pol=4, nbit=2, tscr=2, interval=0.0),
     dict(nchan=32, freq_res=64, nbit=16, interval=0.004, const=0, maxb=2),
     dict(nchan=16, dm=1.0, coherent=1, freq=316.0, pol=4, tscr=2, maxb=2),   # the coherent filterbank (K4 writes the rows) into the scan's columns
-    dict(nchan=128, freq_res=512, overlap=160 | (3 << 16) | (1 << 24)),   # two lanes, K2 on the back lane, three batches per IF (emulator: queue order)
-    dict(nchan=128, freq_res=512, pol=5, overlap=192 | (2 << 24)),         # two lanes, the digitiser beside the next IF's K1
-    dict(nchan=128, freq_res=512, pol=5, overlap=176 | (3 << 24)),         # ... on plain streams (mode 3: the automatic setting's chain)
+    dict(nchan=128, freq_res=512, pol=5, overlap=176 | (3 << 24)),         # the digitiser beside the next IF's K1 on plain streams (mode 3: the automatic setting's chain; emulator: queue order)
 ])
 def test_scan_device_rows_are_the_splice_of_the_per_if_rows(emu_lib, kw):
     """frbch_scan_device: every IF's rows land in its columns of one row buffer == the per-IF outputs side by side."""

@@ -45,10 +45,17 @@ def test_hdr_values_that_do_not_fit_are_argument_errors(tmp_path, hip_lib):
 
 
 def test_unknown_flag_bits_are_rejected(emu_lib):
-    for bad in (1 << 8, 1 << 12, 1 << 19, 1 << 26, 1 << 31):
+    # ablations (8..19), rejected kernel variants / layouts / lane modes kept for A/B runs (4 .. 128, 21, 23 .. 26): experiments builds only
+    for bad in (1 << 8, 1 << 12, 1 << 19, 4, 8, 16, 32, 64, 128, 1 << 21, 1 << 23, 1 << 24, 1 << 25, 1 << 26, 1 << 31):
         with pytest.raises(ch.InputError, match="unknown bit"):
             ch.Channeliser(ch.new_config(emu_lib, flags=bad), emu_lib)
-    ch.Channeliser(ch.new_config(emu_lib, flags=(1 << 20) | (1 << 22) | (1 << 25)), emu_lib).close()
+    for ov in (160 | (1 << 24), 192 | (2 << 24), 176 | (3 << 24) | (2 << 16)):      # CU-masked lanes, forced batching
+        cfg = ch.new_config(emu_lib)
+        cfg.overlap = ov
+        with pytest.raises(ch.InputError, match="overlap"):
+            ch.Channeliser(cfg, emu_lib)
+    # the four production switches (and, in this test-only build, the whole-file paths without their threads)
+    ch.Channeliser(ch.new_config(emu_lib, flags=1 | 2 | (1 << 20) | (1 << 27) | (1 << 22)), emu_lib).close()
 
 
 def test_product_library_is_not_an_experiments_build(hip_lib):
