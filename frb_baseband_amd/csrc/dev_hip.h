@@ -1,4 +1,4 @@
-// gfx950 device layer for frbch_engine.cpp: kernel macro layer, launches, memory, events.
+// gfx950 device layer for the translation units of libfrbch (frbch_internal.h): kernel macro layer, launches, memory, events.
 #ifndef FRBCH_DEV_HIP_H
 #define FRBCH_DEV_HIP_H
 #include <hip/hip_runtime.h>
