@@ -23,21 +23,43 @@ def make_states(nsamp: int, *, if_index: int = 0, nchan: int = 1024, tone_amp: f
     rng = np.random.default_rng([SEED_BASE + if_index, chunk])
     x = rng.standard_normal((2, nsamp), dtype=np.float32)
     if tone_amp:
+        # tone at the centre of channel k: phase 2 pi (k + 1/2) n / (2 nchan) = 2 pi ((2k + 1) n mod 4 nchan) / (4 nchan) -- exact in
+        # integers, so a table of 4 nchan entries replaces cos / sin of every sample (4 s per second of a 32 MHz IF before)
         k = nchan // 3
-        n = np.arange(sample0, sample0 + nsamp, dtype=np.float64)
-        ph = 2.0 * np.pi * ((k + 0.5) / (2.0 * nchan)) * n
-        x[0] += (tone_amp * np.sqrt(2.0) * np.cos(ph)).astype(np.float32)
-        x[1] += (tone_amp * np.sqrt(2.0) * np.sin(ph)).astype(np.float32)
+        period = 4 * nchan
+        idx = ((2 * k + 1) * np.arange(sample0, sample0 + nsamp, dtype=np.int64)) % period
+        tab = 2.0 * np.pi * np.arange(period, dtype=np.float64) / period
+        x[0] += (tone_amp * np.sqrt(2.0) * np.cos(tab)).astype(np.float32)[idx]
+        x[1] += (tone_amp * np.sqrt(2.0) * np.sin(tab)).astype(np.float32)[idx]
     if impulse_at is not None and sample0 <= impulse_at < sample0 + nsamp:
         x[:, impulse_at - sample0] = 10.0
     return quantise_2bit(x)
+
+
+_CACHE: dict = {}          # the last few streams of a second or more (the test suites ask for the same 10-s IFs again and again)
+_CACHE_MAX_BYTES = 3 << 30
 
 
 def make_vdif(seconds: float, *, bw_mhz: float = 32.0, if_index: int = 0, nchan: int = 1024,
               tone_amp: float = 0.1, payload_bytes: int = vdif.DEFAULT_PAYLOAD, legacy: int = 0,
               seconds0: int = 1000, ref_epoch: int = 40, extra_frames: int = 0, bits: int = 2) -> np.ndarray:
     """Whole per-IF file as a uint8 array: ``seconds`` of data (+ ``extra_frames``; the reference's
-    split adds 16, spif2file.sh:151), starting on a second boundary (spif2file.sh:148)."""
+    split adds 16, spif2file.sh:151), starting on a second boundary (spif2file.sh:148).  Streams of a second or more are kept
+    (read-only) and returned again for the same arguments."""
+    key = (float(seconds), float(bw_mhz), if_index, nchan, float(tone_amp), payload_bytes, legacy, seconds0, ref_epoch, extra_frames, bits)
+    if key in _CACHE:
+        return _CACHE[key]
+    out = _make_vdif(seconds, bw_mhz=bw_mhz, if_index=if_index, nchan=nchan, tone_amp=tone_amp, payload_bytes=payload_bytes,
+                     legacy=legacy, seconds0=seconds0, ref_epoch=ref_epoch, extra_frames=extra_frames, bits=bits)
+    if seconds >= 1.0:
+        out.flags.writeable = False
+        while _CACHE and sum(v.nbytes for v in _CACHE.values()) + out.nbytes > _CACHE_MAX_BYTES:
+            _CACHE.pop(next(iter(_CACHE)))
+        _CACHE[key] = out
+    return out
+
+
+def _make_vdif(seconds, *, bw_mhz, if_index, nchan, tone_amp, payload_bytes, legacy, seconds0, ref_epoch, extra_frames, bits):
     fps = vdif.frames_per_second(bw_mhz, payload_bytes, bits)
     nfr = int(round(seconds * fps)) + extra_frames
     spf = payload_bytes * (4 // bits)            # dual-pol time samples per frame

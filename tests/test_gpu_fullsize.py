@@ -254,7 +254,14 @@ def test_config3_full_length_scan_properties(hip_lib, ten_seconds):
     (1) every IF's columns of the scan's row buffer are bit-identical to that IF channelised alone (packed rows),
     (2) run-to-run bit identical, (3) the frozen-scale path (K2 digitises) reproduces the buffered first interval,
     (4) Stokes identity: every (time sample, channel) is ONE Jones vector, so I^2 = Q^2 + U^2 + V^2 to fp32 rounding."""
-    raws = [ten_seconds, synth.make_vdif(10.0, bw_mhz=32.0, nchan=1024, if_index=2), synth.make_vdif(10.0, bw_mhz=32.0, nchan=1024, if_index=3)]
+    # IFs 2 and 3: the same 10 s with the payloads of the frames rotated by 1000 / 2500 frames (other data in every block; the device
+    # path takes frames as they are) -- generating two more 10-s streams cost 70 s of host time
+    fr = ten_seconds.reshape(-1, 8032)
+    raws = [ten_seconds]
+    for shift in (1000, 2500):
+        other = fr.copy()
+        other[:, 32:] = np.roll(fr[:, 32:], shift, axis=0)
+        raws.append(other.reshape(-1))
     bufs = [DeviceBuffer.from_numpy(r) for r in raws]
     nfr = raws[0].size // 8032
     chans = [ch.Channeliser(pu.lib_cfg(hip_lib, -32.0 if i % 2 else 32.0, 1024, 10.0, pol=5), hip_lib) for i in range(3)]
@@ -304,7 +311,10 @@ def test_config4_full_length_parseval_and_determinism(hip_lib):
     samples): Parseval per block on the float power (as test_parseval_every_block_full_size), `-t 8` codes run-to-run
     identical and equal between the buffered first interval and the frozen-scale path."""
     bw, nchan, r = 64.0, 4096, 8192
-    raw = synth.make_vdif(10.0, bw_mhz=bw, nchan=nchan)
+    # 10 s = 19 blocks of 2^26 samples: two generated seconds, repeated (the blocks straddle the seams, so no two are alike; the
+    # properties below hold for any bytes, and generating 10 s of a 64 MHz IF cost a minute of host time)
+    two = synth.make_vdif(2.0, bw_mhz=bw, nchan=nchan)
+    raw = np.tile(two, 5)
     n = 2 * nchan * r
     payload = o.strip_frames(raw, 8032, 32)
     nblocks = payload.size * 2 // n

@@ -75,12 +75,12 @@ CASES = [
     (64.0, 4096, 0.55, dict(tscr=8, flags=3)),                # the same through the generic kernels
     (-64.0, 4096, 0.55, {}),                                  # M = 32, -t 1, LSB: wave K2 (frbch_k2_wave<5,8,2,4>, two time samples per workgroup, sums fused)
     (64.0, 4096, 0.55, dict(tscr=2, nbit=-32)),               # the same with -t 2 (one output row per tile)
-    (64.0, 4096, 1.1, dict(pol=1, nbit=16)),                  # the same kernel family, single-product instantiation, 2 blocks, USB
+    (64.0, 4096, 0.55, dict(pol=1, nbit=16)),                 # the same kernel family, single-product instantiation, USB
     (64.0, 4096, 0.55, dict(flags=1 << 20, nbit=2)),          # wave K2 with the separate statistics pass
     (64.0, 4096, 0.55, dict(pol=4, tscr=2, nbit=16)),         # M = 32, coherency products
     (64.0, 4096, 0.55, dict(pol=4, tscr=4)),                  # four products and tscrunch > 2: barrier K2 (two-sample rows) + frbch_k2_scrunch (round 3; generic K2 before)
     (-64.0, 4096, 0.55, dict(pol=5, tscr=8, nbit=16)),        # ... the IQUV spelling of config 4's `-t 8`
-    (64.0, 4096, 1.1, dict(pol=4, tscr=8, interval=0.6, maxb=1)),   # ... the rescale interval ends inside the scan, one block per launch
+    (64.0, 4096, 1.1, dict(pol=4, tscr=8, interval=0.6, maxb=1)),   # ... the rescale interval ends inside the scan, one block per launch (2 blocks)
     # Stokes I,Q,U,V (pol_mode 5, the `-d4 -iquv` extension; north_star "IQUV formation") through every K2 family
     (32.0, 1024, 0.14, dict(pol=5)),                         # wave K2, MSTAT instantiation while the interval is measured
     (-32.0, 1024, 0.14, dict(pol=5, tscr=2, nbit=16)),
