@@ -236,7 +236,10 @@ def launch_ranks(args, argv):
     return 0
 
 
-WIDE_FETCH = ("frbch_k2_wave", "frbch_k2_fast", "frbch_k2_lane", "frbch_k2_scrunch", "frbch_k2c_", "frbch_quantise", "frbch_stats_partial", "frbch_k0_stage", "frbch_k1_wave", "frbch_k1_split")   # (frbch_k2_priv reads 8 bytes per lane: counted as it is)
+# kernels whose streaming reads FETCH_SIZE tallies at half their bytes (gfx950: 128-byte requests counted as 64, MI355X_MICROARCH.md
+# "HBM").  frbch_k2_priv reads 8 bytes per lane, 64-byte runs of lines two waves share: calibrated against its known byte count
+# (tools/pmc.sh, round 4: FETCH_SIZE = 0.50 - 0.56 of the spill it reads), so it takes the same factor
+WIDE_FETCH = ("frbch_k2_", "frbch_k2c_", "frbch_quantise", "frbch_stats_partial", "frbch_k0_stage", "frbch_k1_wave", "frbch_k1_split")
 
 
 def short_kernel_name(profiler_name):

@@ -100,10 +100,11 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
       h->kname[KID_K2] = nm;
     }
 #ifndef FRBCH_NO_FAST
-    if (pl.fast_k2_priv) {
-      snprintf(nm, sizeof nm, "frbch_k2_priv<%d>", h->cfg.pol_mode == 2 ? 2 : (h->cfg.pol_mode >= 4 ? 4 : 0));
-      h->kname[KID_K2] = nm;
-      snprintf(nm, sizeof nm, "frbch_k2_priv<%d,stats>", h->cfg.pol_mode == 2 ? 2 : (h->cfg.pol_mode >= 4 ? 4 : 0));
+    if (pl.fast_k2_priv) {   // (KID_K2 keeps frbch_k2_wave's name: float rows of four products and fallen-back launches run it)
+      const int pmn = h->cfg.pol_mode == 2 ? 2 : (h->cfg.pol_mode >= 4 ? h->cfg.pol_mode : 0);
+      snprintf(nm, sizeof nm, "frbch_k2_priv<%d>", pmn);
+      h->kname[KID_K2P] = nm;
+      snprintf(nm, sizeof nm, "frbch_k2_priv<%d,stats>", pmn);
       h->kname[KID_K2S] = nm;
     }
     if (pl.fast_k2_lane) {

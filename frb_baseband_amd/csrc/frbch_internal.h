@@ -38,10 +38,10 @@
 
 using namespace frbch;
 
-enum { KID_K1 = 0, KID_KC, KID_K2, KID_STATS, KID_QUANT, KID_K3, KID_K4, KID_K0, KID_K2S, KID_COUNT };
+enum { KID_K1 = 0, KID_KC, KID_K2, KID_STATS, KID_QUANT, KID_K3, KID_K4, KID_K0, KID_K2S, KID_K2P, KID_COUNT };
 const char* const kKernelNames[KID_COUNT] = {"frbch_k1_branch", "frbch_kc_dcfix", "frbch_k2_chan",
                                              "frbch_stats", "frbch_quantise", "frbch_k3_dedisp", "frbch_k4_out", "frbch_k0_stage",
-                                             "frbch_k2_statpass"};
+                                             "frbch_k2_statpass", "frbch_k2_priv"};
 static_assert(KID_COUNT <= (int)(sizeof(((frbch_timing*)nullptr)->k) / sizeof(((frbch_timing*)nullptr)->k[0])), "frbch_timing holds every slot");
 
 struct EventPair {

@@ -895,7 +895,12 @@ int launch_back(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
     CHECK_DEV(h, dev_check_launch(), "launch K2c/K3/K4");
     return FRBCH_OK;
   }
-  ProfScope ps(h, s, KID_K2, bytes);
+#ifndef FRBCH_NO_FAST
+  const int kid = priv_takes(pl, p, h->priv_grid) ? KID_K2P : KID_K2;   // the two K2 families of 2C = 2048 report separately
+#else
+  const int kid = KID_K2;
+#endif
+  ProfScope ps(h, s, kid, bytes);
   if (!launch_k2_fast(h, p, nb, s)) DEV_LAUNCH(frbch_k2_chan, pl.r / tile_t, nb, pl.nthreads, pl.k2_lds, s, p);
   CHECK_DEV(h, dev_check_launch(), "launch K2");
   return FRBCH_OK;
