@@ -48,6 +48,7 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
   if (cfg->device >= ndev) return fail(h, FRBCH_E_DEVICE, "device ordinal out of range");
   if (cfg->flags & ~kAcceptedFlags)
     return fail(h, FRBCH_E_ARG, "unknown bit in cfg.flags (kernel variants kept for A/B runs and timing-only ablations exist only in FRBCH_EXPERIMENTS builds)");
+  if ((cfg->flags & kFlagBuffered) && (cfg->flags & kFlagTwoPass)) return fail(h, FRBCH_E_ARG, "cfg.flags asks for the buffered AND the two-pass rescale");
   if (!kExperiments) {   // overlap: automatic (0), off (1), or the plain-stream mode 3 with a CU count; no CU-masked lanes, no forced batching
     const uint32_t mode = (cfg->overlap >> 24) & 0xFFu, batches = (cfg->overlap >> 16) & 0xFFu;
     if ((mode != 0 && mode != 3) || batches)

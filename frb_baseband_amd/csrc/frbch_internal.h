@@ -184,8 +184,9 @@ struct DeviceGuard {
 // and has parity cases.  Everything else -- rejected kernel variants, layouts and lane modes kept for A/B runs, the timing-only
 // ablations of bits 8..19 -- exists only in libraries built with -DFRBCH_EXPERIMENTS; bit 22 (whole-file paths without their
 // reader / writer threads) also in the test-only emulator build.
-constexpr uint32_t kFlagGenericK1 = 1u, kFlagGenericK2 = 2u, kFlagSeparateStats = 1u << 20, kFlagTwoPass = 1u << 27;
-constexpr uint32_t kProductFlags = kFlagGenericK1 | kFlagGenericK2 | kFlagSeparateStats | kFlagTwoPass;
+constexpr uint32_t kFlagGenericK1 = 1u, kFlagGenericK2 = 2u, kFlagSeparateStats = 1u << 20;
+constexpr uint32_t kFlagBuffered = 1u << 27, kFlagTwoPass = 1u << 28;   // form of a first `-c` rescale interval: neither = automatic
+constexpr uint32_t kProductFlags = kFlagGenericK1 | kFlagGenericK2 | kFlagSeparateStats | kFlagBuffered | kFlagTwoPass;
 constexpr uint32_t kFlagNoPipeline = 1u << 22, kFlagNoK0 = 1u << 23, kFlagGenericQuant = 1u << 25;
 [[maybe_unused]] constexpr uint32_t kExperimentFlags = 4u | 8u | 16u | 32u | 64u | 128u | (1u << 21) | (1u << 22) | (1u << 23) | (1u << 24) | (1u << 25) | (1u << 26);
 #ifdef FRBCH_EXPERIMENTS

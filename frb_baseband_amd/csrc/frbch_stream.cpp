@@ -64,13 +64,15 @@ bool fused_ok(const frbch_handle* h) { return h->scale_frozen; }
 // complete, so K2 runs over it twice instead: a statistics-only pass (sums, no rows), frbch_stats_final, then the digitising pass --
 // 18 B per sample, and the SAME float arithmetic in both passes, so the codes are what the buffered form produces from the same
 // offset / scale.  Taken when the interval starts with this batch and either ends inside it or the batch is the last of the call
-// (the flush, or the next call, then finds the batch deferred).  MEASURED SLOWER than the buffered form (round 4):
-// both K2 passes are bound by their waves' instruction chains (~1.5 ms each per IF of config 3), while the buffered form's extra 16 B
-// per sample stream at 5.2 - 5.45 TB/s partly beside the next IF's K1.  Opt-in by flag bit 27; the default stays buffered.
+// (the flush, or the next call, then finds the batch deferred).  Automatic for four products (measured, config 3: 35.3 ms per 8-IF
+// step against 36.0 buffered); one product stays buffered (its float rows are a quarter of the bytes: 3.3
+// against 3.9 ms at config 2).  flags: 1 << 27 forces the buffered form, 1 << 28 the two-pass form.
 bool twopass_usable(const frbch_handle* h) {
   const Plan& pl = h->pl;
-  return pl.fast_k2_priv && h->priv_grid > 0 && h->cfg.rescale_constant && pl.interval_rows > 0 && !pl.k2_two_stage &&
-         (h->cfg.flags & kFlagTwoPass) && fused_chunks_of(h) > 0;
+  if (!(pl.fast_k2_priv && h->priv_grid > 0 && h->cfg.rescale_constant && pl.interval_rows > 0 && !pl.k2_two_stage && fused_chunks_of(h) > 0))
+    return false;
+  if (h->cfg.flags & kFlagBuffered) return false;
+  return (h->cfg.flags & kFlagTwoPass) || pl.nif == 4;
 }
 // second pass over a deferred batch: offset / scale are final, K2 digitises the batch's rows into d_out
 int deferred_emit(frbch_handle* h, uint8_t* d_out, size_t cap, uint64_t* rows_written, dev_stream_t s) {

@@ -63,8 +63,10 @@ typedef struct frbch_config {
   uint32_t flags;              /* 0 in production.  Four kernel-selection switches, every one produces the same (correct) output and
                                 * has parity cases: 1 generic (radix-2) K1, 2 generic K2 and back end -- the cross-check family of
                                 * tests/test_gpu_stress.py --, 1<<20 rescale statistics in a separate pass over the buffered power
-                                * rows instead of inside K2, 1<<27 two-pass rescale of a first `-c` interval (K2 runs twice over the
-                                * resident spill instead of buffering float rows; measured slower).
+                                * rows instead of inside K2, and the form of a first `-c` rescale interval (bits 27 / 28: neither =
+                                * automatic, 1<<27 buffered -- float rows written, then digitised --, 1<<28 two-pass -- K2 runs twice
+                                * over the resident spill, no float rows; automatic = two-pass for four products at 1024 channels,
+                                * DESIGN.md section 5b; both at once is an error).
                                 * Any other bit makes frbch_open fail with FRBCH_E_ARG: rejected kernel variants, layouts and lane
                                 * modes kept for A/B runs and the timing-only ablations (which produce WRONG output) exist only in
                                 * libraries built with -DFRBCH_EXPERIMENTS (make EXPERIMENTS=1), never in the product build. */

@@ -28,11 +28,11 @@ CASES = [
     (32.0, 1024, 0.14, dict(flags=1)),                       # generic K1 + fast K2
     (32.0, 1024, 0.14, dict(flags=2)),                       # fast K1 + generic K2
     (-32.0, 1024, 0.14, dict(pol=4, tscr=2)),                # BASELINE config 3 shape (-d4), LSB, -t 2
-    # two-pass rescale of a first interval (flag 1 << 27): frbch_k2_priv sums only, then digitises the same resident spill
-    (32.0, 1024, 0.14, dict(flags=1 << 27)),                 # the scan ends inside its first interval: second pass at the flush
-    (-32.0, 1024, 0.27, dict(flags=1 << 27, pol=5, interval=0.1)),       # the interval ends inside the (only) batch: statistics over its rows, codes for all
-    (32.0, 1024, 0.27, dict(flags=1 << 27, pol=4, tscr=2, nbit=16, maxb=3)),   # a second batch arrives while the first is deferred: its float rows are written after all
-    (32.0, 1024, 0.27, dict(flags=1 << 27, pol=2, tscr=4, nbit=2, interval=0.1, maxb=2)),   # interval end inside the second batch: buffered form
+    # two-pass rescale of a first interval (flag 1 << 28; automatic with four products): frbch_k2_priv sums only, then digitises the same resident spill
+    (32.0, 1024, 0.14, dict(flags=1 << 28)),                 # the scan ends inside its first interval: second pass at the flush
+    (-32.0, 1024, 0.27, dict(flags=1 << 28, pol=5, interval=0.1)),       # the interval ends inside the (only) batch: statistics over its rows, codes for all
+    (32.0, 1024, 0.27, dict(flags=1 << 28, pol=4, tscr=2, nbit=16, maxb=3)),   # a second batch arrives while the first is deferred: its float rows are written after all
+    (32.0, 1024, 0.27, dict(flags=1 << 28, pol=2, tscr=4, nbit=2, interval=0.1, maxb=2)),   # interval end inside the second batch: buffered form
     (-32.0, 1024, 0.14, dict(pol=4, tscr=4, nbit=-32)),
     (32.0, 1024, 0.14, dict(pol=0, nbit=2, tscr=4)),
     (32.0, 1024, 0.14, dict(tscr=8)),                        # -t 8: 8-sequence K2 workgroups

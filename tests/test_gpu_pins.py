@@ -55,8 +55,10 @@ def _unpack_codes(buf, nbit, shape):
     (32.0, 1024, 0.27, 2, 8, 1, 3),            # generic kernels
     (32.0, 1024, 0.2, 2, 8, 16, 0),            # frbch_quantise_fast: fewer rows (384) than row phases: only its checked tail runs
     (32.0, 1024, 0.6, 5, 8, 1, 0),             # ... 9 blocks: an even number of pipelined trips + left-over steps
-    (32.0, 1024, 0.27, 5, 8, 1, 1 << 27),      # two-pass rescale: both passes of frbch_k2_priv compute the same floats
-    (-32.0, 1024, 0.27, 2, 8, 2, 1 << 27),
+    (32.0, 1024, 0.27, 5, 8, 1, 1 << 28),      # two-pass rescale: both passes of frbch_k2_priv compute the same floats
+    (-32.0, 1024, 0.27, 2, 8, 2, 1 << 28),
+    (-32.0, 1024, 0.27, 4, 8, 1, 1 << 27),     # the buffered form where two-pass is automatic: float rows by frbch_k2_wave, lean digitiser
+    (32.0, 1024, 0.27, 5, 16, 1, 1 << 27),     # ... generic digitiser (16 bit)
 ])
 def test_rescale_and_digitiser_are_bit_exact_on_the_hip_floats(hip_lib, bw, nchan, secs, pol, nbit, tscr, flags):
     raw = synth.make_vdif(secs, bw_mhz=abs(bw), nchan=nchan)
@@ -505,9 +507,10 @@ def test_scan_device_config3_as_stated_against_the_oracle(hip_lib):
 
 
 @pytest.mark.parametrize("overlap,kw", [
-    (192 | (3 << 24), dict(pol=5)),                                            # the digitiser beside the next IF's K1, its CUs held by an LDS reservation
+    (192 | (3 << 24), dict(pol=5, flags=1 << 27)),                             # the digitiser beside the next IF's K1, its CUs held by an LDS reservation (buffered form forced)
     (160 | (3 << 24), dict(pol=2, interval=0.1, const=0, maxb=2)),             # ... an interval per 0.1 s (the power buffer is re-used)
-    (0, dict(pol=5, interval=0.1, maxb=2)),                                    # the automatic setting, the interval ends inside the scan
+    (0, dict(pol=5, interval=0.1, maxb=2, flags=1 << 27)),                     # the automatic overlap, the interval ends inside the scan
+    (0, dict(pol=5)),                                                          # the automatic rescale form (two-pass: no digitiser to overlap)
 ])
 def test_scan_device_lanes_give_the_same_rows(hip_lib, overlap, kw):
     """two kernels sharing the chip changes WHERE and WHEN kernels run, never what they write: rows identical to the run without

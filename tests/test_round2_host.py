@@ -56,6 +56,9 @@ def test_unknown_flag_bits_are_rejected(emu_lib):
             ch.Channeliser(cfg, emu_lib)
     # the four production switches (and, in this test-only build, the whole-file paths without their threads)
     ch.Channeliser(ch.new_config(emu_lib, flags=1 | 2 | (1 << 20) | (1 << 27) | (1 << 22)), emu_lib).close()
+    ch.Channeliser(ch.new_config(emu_lib, flags=1 << 28), emu_lib).close()
+    with pytest.raises(ch.InputError, match="buffered AND"):
+        ch.Channeliser(ch.new_config(emu_lib, flags=(1 << 27) | (1 << 28)), emu_lib)
 
 
 def test_product_library_is_not_an_experiments_build(hip_lib):
