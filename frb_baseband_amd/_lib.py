@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FRBCH_LIB: another build of the same library for this process (the profiling build `make exp`); default: the product
 LIB_PATH = os.environ.get("FRBCH_LIB") or os.path.join(_HERE, "csrc", "libfrbch.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 OK, E_ARG, E_IO, E_FORMAT, E_DEVICE, E_NOMEM, E_STATE, E_CAPACITY = 0, -1, -2, -3, -4, -5, -6, -7
 
@@ -31,6 +31,8 @@ class FrbchConfig(C.Structure):
         ("ra", C.c_char * 32), ("dec", C.c_char * 32), ("datafile", C.c_char * 512),
         ("input_bits", C.c_uint32), ("overlap", C.c_uint32),
         ("levels", C.c_float * 4),
+        ("unpack_mode", C.c_uint32), ("dls_nsample", C.c_uint32),
+        ("dls_cutoff_sigma", C.c_float), ("dls_threshold", C.c_float),
     ]
 
 

@@ -30,9 +30,9 @@ void mark_user_stream(frbch_handle* h, dev_stream_t s) {
 using namespace frbchi;
 
 #ifdef FRBCH_EXPERIMENTS
-extern "C" const char* frbch_version(void) { return "frbch abi 4 backend " FRBCH_BACKEND_NAME " +experiments"; }
+extern "C" const char* frbch_version(void) { return "frbch abi 5 backend " FRBCH_BACKEND_NAME " +experiments"; }
 #else
-extern "C" const char* frbch_version(void) { return "frbch abi 4 backend " FRBCH_BACKEND_NAME; }
+extern "C" const char* frbch_version(void) { return "frbch abi 5 backend " FRBCH_BACKEND_NAME; }
 #endif
 
 extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
@@ -59,6 +59,7 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
   char arch[128] = "";
   if (!dev_arch_ok(h->device, arch, sizeof arch, &h->lds_limit)) return fail(h, FRBCH_E_DEVICE, "cannot query device");
   h->lane_ncu = dev_cu_count(h->device);
+  if (h->cfg.unpack_mode == 1) h->cfg.flags |= kFlagGenericK1;   // the per-window levels are looked up by the generic K1 only
   const std::string why = make_plan(h->cfg, &h->pl, h->lds_limit);
   if (!why.empty()) return fail(h, FRBCH_E_ARG, why);
   const Plan& pl = h->pl;
@@ -132,6 +133,14 @@ extern "C" int frbch_open(const frbch_config* cfg, frbch_handle** out) {
     if (pl.ncol % 64 == 0 && pl.rows_per_block % 2 == 0 && pl.c % 4 == 0 && !(h->cfg.flags & 2u)) h->kname[KID_K4] = "frbch_k4_fast";
     if (pl.coh_fast_r) h->kname[KID_K3] = (pl.coh_fast_r == 4 && pl.coh_nt == 512 && !(h->cfg.flags & 8u)) ? "frbch_k3_wave<4>" : "frbch_k3_fast";
   }
+  if (pl.dls_lg_ns) {
+    const std::vector<float> tab = dls_table(1u << pl.dls_lg_ns, h->cfg.dls_cutoff_sigma, h->cfg.dls_threshold);
+    CHECK_DEV(h, dev_malloc((void**)&h->dls_tab, tab.size() * sizeof(float)), "hipMalloc(level table)");
+    CHECK_DEV(h, dev_h2d(h->dls_tab, tab.data(), tab.size() * sizeof(float), h->stream), "upload level table");
+    CHECK_DEV(h, dev_sync(h->stream), "sync");
+    h->dls_cap = (((uint64_t)pl.maxb - 1) * pl.hop + pl.n) >> pl.dls_lg_ns;
+    CHECK_DEV(h, dev_malloc((void**)&h->dls_nlow, h->dls_cap * sizeof(uint32_t)), "hipMalloc(window counts)");
+  }
   CHECK_DEV(h, dev_malloc((void**)&h->offset, pl.ncol * sizeof(float)), "hipMalloc(offset)");
   CHECK_DEV(h, dev_malloc((void**)&h->scale, pl.ncol * sizeof(float)), "hipMalloc(scale)");
   if ((rc = set_identity_rescale(h))) return rc;
@@ -155,6 +164,7 @@ extern "C" void frbch_close(frbch_handle* h) {
   dev_free(h->spill2); dev_free(h->chirp); dev_free(h->ptmp); dev_free(h->scr2);
   dev_free(h->offset); dev_free(h->scale); dev_free(h->powbuf); dev_free(h->partial);
   dev_free(h->d_frames); dev_free(h->d_out); dev_free(h->stg); dev_free(h->d_fbad); dev_free(h->scan_rows);
+  dev_free(h->dls_tab); dev_free(h->dls_nlow);
   for (int i = 0; i < 8; ++i) { dev_host_free(h->pin_in[i]); dev_host_free(h->pin_out[i]); }
   if (h->stream) dev_stream_destroy(h->stream);
   if (h->user_ev_made) dev_event_destroy(h->user_ev);

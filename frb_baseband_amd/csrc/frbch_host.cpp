@@ -149,6 +149,16 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
   pl->hop = (uint64_t)pl->c2 * (uint64_t)pl->keep;
   pl->block_stride_bytes = pl->hop * (uint64_t)in_bits / 4;
   pl->rows_per_block = (uint64_t)pl->keep / t;
+  pl->dls_lg_ns = 0;
+  if (cfg.unpack_mode > 1) return "unpack_mode must be 0 (static level table) or 1 (dynamic level setting)";
+  if (cfg.unpack_mode == 1) {
+    const uint32_t ns = cfg.dls_nsample ? cfg.dls_nsample : 512u;
+    if (in_bits != 2) return "dynamic level setting needs 2-bit input (a 1-bit sample has no magnitude)";
+    if (!is_pow2(ns) || ns < 16 || ns > 8192) return "dls_nsample must be a power of two in [16, 8192]";
+    if (pl->n % ns || pl->hop % ns) return "dls_nsample must divide the block length and the distance between block starts";
+    if (cfg.dls_threshold < 0.f || cfg.dls_threshold > 4.f) return "dls_threshold must lie in (0, 4] (0 = 0.9674)";
+    pl->dls_lg_ns = ilog2(ns);
+  }
   pl->k3_lds = 2 * (size_t)(r + 1) * 8;
   pl->k4_lds = 64 * 65 * 4;
   if (pl->coherent && pl->k3_lds > lds_limit) return "freq_res too large for the LDS of this device";
@@ -425,6 +435,49 @@ std::string make_plan(const frbch_config& cfg, Plan* pl, size_t lds_limit, int i
   return "";
 }
 
+// ---------------------------------------------------------------------------------------------
+// Dynamic level setting (frbch_config.unpack_mode 1): the table the unpack looks its two output levels up in.
+// A Gaussian voltage of rms s sampled with threshold t falls inside the threshold with probability Phi = erf(t / (s sqrt 2)); the
+// mean power of the samples inside is s^2 (1 - g / Phi), of those outside s^2 (1 + g / (1 - Phi)), g = sqrt(2 / pi) u exp(-u^2 / 2),
+// u = t / s.  A window with k of L samples inside estimates Phi = k / L, hence u = sqrt 2 erfinv(Phi) and s = t / u (t in units of the
+// nominal rms: cfg.dls_threshold); its output levels are the roots of those two mean powers, so that Phi lo^2 + (1 - Phi) hi^2 = s^2:
+// the unpacked power follows the undigitised power (Jenet & Anderson 1998, PASP 110, 1467: dynamic level setting with
+// power-conserving output levels; the formulas are this build's restatement, DESIGN.md section 2a -- DSPSR is absent).
+// Windows whose count is further than `cutoff` standard deviations sqrt(L Phi0 (1 - Phi0)) from L Phi0, Phi0 = erf(t / sqrt 2), and the
+// counts 0 and L (no estimate) get (0, 0): zeroed.  (The test oracle restates this table; tests/test_dynamic_levels.py compares.)
+// ---------------------------------------------------------------------------------------------
+static double erfinv_unit(double y) {   // y in (0, 1)
+  const double a = 0.147, l = log((1.0 - y) * (1.0 + y)), b = 2.0 / (M_PI * a) + 0.5 * l;
+  double x = sqrt(sqrt(b * b - l / a) - b);   // (Winitzki's approximation: the start of the Newton iteration)
+  for (int it = 0; it < 80; ++it) {
+    const double err = erf(x) - y;
+    const double step = err / (2.0 / sqrt(M_PI) * exp(-x * x));
+    x -= step;
+    if (fabs(step) <= 1e-16 * fabs(x)) break;
+  }
+  return x;
+}
+std::vector<float> dls_table(uint32_t nsample, float cutoff_sigma, float threshold) {
+  const double thr = threshold > 0.f ? (double)threshold : 0.9674;
+  const double cutoff = cutoff_sigma == 0.f ? 10.0 : (double)cutoff_sigma;
+  const double phi0 = erf(thr / sqrt(2.0)), mean = nsample * phi0, sd = sqrt(nsample * phi0 * (1.0 - phi0));
+  long kmin = 1, kmax = (long)nsample - 1;
+  if (cutoff > 0) {
+    kmin = std::max<long>(kmin, (long)ceil(mean - cutoff * sd));
+    kmax = std::min<long>(kmax, (long)floor(mean + cutoff * sd));
+  }
+  std::vector<float> tab(2 * ((size_t)nsample + 1), 0.f);
+  for (long k = kmin; k <= kmax; ++k) {
+    const double phi = (double)k / (double)nsample;
+    const double u = sqrt(2.0) * erfinv_unit(phi);
+    const double sig = thr / u;
+    const double g = sqrt(2.0 / M_PI) * u * exp(-0.5 * u * u);
+    tab[2 * k] = (float)(sig * sqrt(1.0 - g / phi));
+    tab[2 * k + 1] = (float)(sig * sqrt(1.0 + g / (1.0 - phi)));
+  }
+  return tab;
+}
+
 void fill_twiddles(float* dst, uint64_t n, uint64_t count, uint64_t step) {
   for (uint64_t k = 0; k < count; ++k) {
     const uint64_t q = (k * step) % n;
@@ -615,6 +668,10 @@ extern "C" int frbch_parse_digifil_argv(int argc, const char* const* argv, frbch
     if (tok == "-cont") continue;                       // contiguous input: what we assume anyway
     else if (tok == "-c") cfg->rescale_constant = 1;
     else if (tok == "-2") continue;                     // 2-bit excision off: static level table
+    // DSPSR's unpacker options, attached to the -2: any of them selects the dynamic level setting (cfg.unpack_mode 1)
+    else if (tok.compare(0, 3, "-2n") == 0 && tok.size() > 3) { cfg->unpack_mode = 1; cfg->dls_nsample = (uint32_t)atoi(tok.c_str() + 3); }
+    else if (tok.compare(0, 3, "-2c") == 0 && tok.size() > 3) { cfg->unpack_mode = 1; cfg->dls_cutoff_sigma = (float)atof(tok.c_str() + 3); }
+    else if (tok.compare(0, 3, "-2t") == 0 && tok.size() > 3) { cfg->unpack_mode = 1; cfg->dls_threshold = (float)atof(tok.c_str() + 3); }
     else if (tok == "-iquv") want_iquv = true;          // extension: Stokes I,Q,U,V from the -d4 products (pol_mode 5)
     else if (tok == "-threads") { ok = opt_value(tok, 8, argc, argv, &i, &val); }
     else if (tok.compare(0, 2, "-b") == 0) { ok = opt_value(tok, 2, argc, argv, &i, &val); cfg->nbit_out = atoi(val.c_str()); }

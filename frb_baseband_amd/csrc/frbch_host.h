@@ -68,6 +68,7 @@ struct Plan {
   double tsamp_s;
   double fch1, foff;
   float digi_mean, digi_scale, digi_max;
+  int dls_lg_ns;              // dynamic level setting (cfg.unpack_mode 1): log2 of the window length in samples; 0 = static table
 };
 
 // returns "" on success, else the reason (InputError territory)
@@ -82,6 +83,10 @@ constexpr uint32_t kMaxCoherentFreqRes = 8192;
 std::vector<uint8_t> sigproc_header(const frbch_config& cfg, const Plan& plan, double tstart_mjd, int nchans_total = 0);
 double sigproc_angle(const char* text);
 int sigproc_telescope_id(const char* name);
+
+// dynamic level setting: output levels (low, high) per low-state count 0..nsample of a window, [nsample + 1][2] (DESIGN.md
+// section 2a; (0, 0) = the window is zeroed); cutoff_sigma < 0 = no excision
+std::vector<float> dls_table(uint32_t nsample, float cutoff_sigma, float threshold);
 
 // exp(-2 pi i k / n) for k in [0, count), evaluated in double, stored as float pairs
 void fill_twiddles(float* dst_xy, uint64_t n, uint64_t count, uint64_t step);

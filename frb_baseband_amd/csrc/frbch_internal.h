@@ -107,6 +107,9 @@ struct frbch_handle {
   uint64_t frames_seen = 0, frames_invalid = 0, frame_gaps = 0, frames_filled = 0;
   std::vector<uint8_t> carry_bad;  // per frame of `carry`: 1 = flagged invalid, or a filler inserted for a missing frame number
   uint32_t* d_fbad = nullptr;      // bitmap of those flags for the frames of the launch in progress
+  float* dls_tab = nullptr;        // dynamic level setting (cfg.unpack_mode 1): [nsample + 1][2] output levels; null = static table
+  uint32_t* dls_nlow = nullptr;    // ... low-state counts of the windows of the launch in progress (frbch_dls_count)
+  uint64_t dls_cap = 0;            // ... windows it holds
   size_t d_fbad_words = 0;
   uint64_t next_frame_index = 0;   // seconds*fps + frame_nr expected next
   size_t checked_bytes = 0;        // prefix of `carry` whose headers were already checked
@@ -277,6 +280,7 @@ int allow_generic_lds(frbch_handle* h);                      // LDS sizes of the
 int setup_fast(frbch_handle* h);                             // tables and LDS sizes of the register-pass kernels
 int build_chirp(frbch_handle* h, int order_m);
 int launch_front(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s, dev_stream_t sk);   // K0, K1, Kc
+int launch_dls_count(frbch_handle* h, KParams& p, uint64_t nsamples, dev_stream_t s);            // dynamic level setting: the windows' low-state counts
 int launch_back(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s);                     // K2 (or K2c, K3, K4)
 int launch_unpack_tap(frbch_handle* h, KParams& p, uint64_t nsamples, int decoder, dev_stream_t s);
 int fused_chunks_of(const frbch_handle* h);                  // rows of partial rescale sums K2 may write (0: it cannot sum)

@@ -95,6 +95,13 @@ struct KParams {
   const uint32_t* fbad;       // generic K1 only: bitmap over the frames of `frames` (bit f = frame f is flagged invalid or is a
                               // filler for a missing frame): its samples enter the filterbank as 0.  null = every frame is good
   uint64_t fbad_frame0;       // index, inside the bitmap, of the frame `frames` points at
+  // ---- dynamic level setting (frbch_config.unpack_mode 1; generic K1 and the unpack tap) ---------------------------------------
+  uint32_t* dls_nlow;         // [window] low-state counts of the windows of this launch: pol 0 | pol 1 << 16 (frbch_dls_count writes,
+                              // the unpack reads); window w = samples [w << dls_lg_ns, (w + 1) << dls_lg_ns) counted from the launch's
+                              // first sample (block starts are multiples of the window: frbch_host.cpp checks)
+  const float* dls_tab;       // [nsample + 1][2]: output levels (low, high) for a window with that many low-state samples; (0, 0) for
+                              // counts outside the accepted range (the window is zeroed).  null = the static table `lut`
+  int dls_lg_ns;              // log2(window length in samples)
 };
 
 struct StatParams {

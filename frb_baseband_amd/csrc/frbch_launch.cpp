@@ -805,9 +805,35 @@ int build_chirp(frbch_handle* h, int order_m) {
 
 dev_event_t pool_event(frbch_handle* h);
 // K0 + K1 + Kc over nb blocks: frames -> spill, P0.  K0 may run on another stream (`sk`, the back lane's CUs): K1 waits for it.
+// dynamic level setting: the low-state counts of the windows covering the launch's first `nsamples` samples (a multiple of the window)
+int launch_dls_count(frbch_handle* h, KParams& p, uint64_t nsamples, dev_stream_t s) {
+  const Plan& pl = h->pl;
+  const uint64_t nwin = nsamples >> pl.dls_lg_ns;
+  if (!h->dls_tab || (nwin << pl.dls_lg_ns) != nsamples) return fail(h, FRBCH_E_ARG, "dynamic level setting: the sample count is not a multiple of the window");
+  if (nwin > h->dls_cap) {
+    dev_free(h->dls_nlow);
+    h->dls_nlow = nullptr;
+    h->dls_cap = 0;
+    CHECK_DEV(h, dev_malloc((void**)&h->dls_nlow, nwin * sizeof(uint32_t)), "hipMalloc(window counts)");
+    h->dls_cap = nwin;
+  }
+  p.dls_tab = h->dls_tab;
+  p.dls_nlow = h->dls_nlow;
+  p.dls_lg_ns = pl.dls_lg_ns;
+  KParams q = p;
+  q.row0 = nwin;
+  DEV_LAUNCH(frbch_dls_count, (nwin + 3) / 4, 1, 256, 2048, s, q);
+  CHECK_DEV(h, dev_check_launch(), "launch window counts");
+  return FRBCH_OK;
+}
+
 int launch_front(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s, dev_stream_t sk) {
   const Plan& pl = h->pl;
   p.tile_major = 0;   // set by the K1 that writes that layout
+  if (pl.dls_lg_ns) {
+    const int rc = launch_dls_count(h, p, ((uint64_t)nb - 1) * pl.hop + pl.n, s);
+    if (rc) return rc;
+  }
   {
     // blocks that touch invalid / filler frames: the staged wave K1 reads their samples as 0 through a flag per row (MSK);
     // where it cannot run (R = 8192, unaligned input, the barrier K1) the generic K1 tests the bitmap per sample
@@ -1120,6 +1146,11 @@ int fused_chunks_of(const frbch_handle* h) {
 
 // the unpack tap: voltages as the filterbank sees them (A4 in isolation)
 int launch_unpack_tap(frbch_handle* h, KParams& p, uint64_t nsamples, int decoder, dev_stream_t s) {
+  if (h->pl.dls_lg_ns) {
+    if (decoder != 0) return fail(h, FRBCH_E_ARG, "dynamic level setting is decoded by the generic unpack only");
+    const int rc = launch_dls_count(h, p, nsamples, s);
+    if (rc) return rc;
+  }
   if (decoder == 0) {
     DEV_LAUNCH(frbch_unpack_tap, (nsamples + 255) / 256, 1, 256, 0, s, p);
   } else {

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define FRBCH_ABI_VERSION 4
+#define FRBCH_ABI_VERSION 5
 
 /* error codes (negative); 0 = ok.  process_vdif.py:193-198 turns a non-zero digifil exit status
  * into RunError; the CLI shim maps any of these to exit status 1 with frbch_strerror on stderr. */
@@ -86,6 +86,18 @@ typedef struct frbch_config {
   float levels[4];             /* 2-bit level table, state 0..3 -> voltage (process_vdif.py:157 passes the bare `-2`: DSPSR's
                                 * static table); all four 0 = the default -3.3359, -1, +1, +3.3359.  A run-time table in
                                 * every kernel, so another level scheme is a data change.                                  */
+  uint32_t unpack_mode;        /* 0 = the static table above (what this build takes the bare `-2` of process_vdif.py:157,160 to
+                                * mean).  1 = DYNAMIC LEVEL SETTING after Jenet & Anderson (1998): per window of dls_nsample
+                                * consecutive samples of one polarisation the number of low-state samples estimates the undigitised
+                                * power, and the window's two output levels are the power-conserving ones for that estimate (formulas:
+                                * DESIGN.md section 2a, restated in oracle/frb_oracle.py dls_table).  An OPTION for sites that find
+                                * their digifil does this (SURVEY section 7 hard part 2; unpinnable here: DSPSR is absent): 2-bit
+                                * input only, through the generic K1 (slower, section 2a).  The digifil shim selects it with
+                                * `-2n<nsample>`, `-2c<cutoff>` or `-2t<threshold>` (DSPSR's spelling of the unpacker options).       */
+  uint32_t dls_nsample;        /* window length in samples; 0 = 512.  A power of two in 16..8192 that divides the block length   */
+  float dls_cutoff_sigma;      /* windows whose low-state count lies further than this many standard deviations from the count a
+                                * Gaussian signal at the nominal threshold gives are zeroed (impulsive interference); 0 = 10; < 0 = off */
+  float dls_threshold;         /* sampler threshold in units of the nominal rms; 0 = 0.9674 (the optimum for four levels)        */
 } frbch_config;
 
 typedef struct frbch_handle frbch_handle;

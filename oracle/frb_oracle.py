@@ -182,6 +182,67 @@ def unpack_2bit(payload: np.ndarray, levels=None) -> np.ndarray:
     return out
 
 
+# --------------------------------------------------------------------------------------------
+# 2-bit unpack with DYNAMIC LEVEL SETTING (optional: frbch_config.unpack_mode 1, include/frbch.h)
+# --------------------------------------------------------------------------------------------
+# SURVEY section 7 (hard part 2) flags that DSPSR's two-bit unpacker may set its output levels per window of the input (Jenet &
+# Anderson 1998, PASP 110, 1467) instead of reading the static table above; the reference only passes the bare `-2`
+# (process_vdif.py:157,160) and DSPSR is absent, so WHICH it does cannot be settled here.  This is the restatement of the
+# dynamic scheme this build offers as an option, so that a site can compare both against a real digifil output.  [EXT-UNVERIFIED]
+#   * a window = `nsample` consecutive samples of ONE polarisation, counted from the first sample handed to the filterbank (after -S);
+#   * k = samples of the window in a low state (offset binary 1, 2); Phi = k / nsample estimates erf(t / (s sqrt 2)) for a Gaussian
+#     voltage of rms s and sampler threshold t, hence u = t / s = sqrt 2 erfinv(Phi) and s = t / u, t = `threshold` nominal rms;
+#   * the window's output levels conserve the mean power of the two regions of that Gaussian:
+#       lo^2 = s^2 (1 - g / Phi),   hi^2 = s^2 (1 + g / (1 - Phi)),   g = sqrt(2 / pi) u exp(-u^2 / 2)
+#     (so Phi lo^2 + (1 - Phi) hi^2 = s^2: the unpacked power follows the undigitised power);
+#   * windows with k further than `cutoff_sigma` x sqrt(L Phi0 (1 - Phi0)) from L Phi0, Phi0 = erf(threshold / sqrt 2), and k = 0 or L,
+#     are zeroed (impulsive interference excision).
+DLS_THRESHOLD = 0.9674
+DLS_NSAMPLE = 512
+DLS_CUTOFF_SIGMA = 10.0
+
+
+def dls_table(nsample: int = DLS_NSAMPLE, cutoff_sigma: float = DLS_CUTOFF_SIGMA, threshold: float = DLS_THRESHOLD) -> np.ndarray:
+    """f32[nsample + 1][2]: (low, high) output level of a window with k low-state samples; (0, 0) = window zeroed.
+    cutoff_sigma < 0: no excision (only k = 0 and k = nsample are zeroed)."""
+    from scipy.special import erf, erfinv
+    thr = float(threshold)
+    phi0 = float(erf(thr / np.sqrt(2.0)))
+    mean, sd = nsample * phi0, np.sqrt(nsample * phi0 * (1.0 - phi0))
+    kmin, kmax = 1, nsample - 1
+    if cutoff_sigma > 0:
+        kmin = max(kmin, int(np.ceil(mean - cutoff_sigma * sd)))
+        kmax = min(kmax, int(np.floor(mean + cutoff_sigma * sd)))
+    tab = np.zeros((nsample + 1, 2), dtype=np.float32)
+    k = np.arange(kmin, kmax + 1, dtype=np.float64)
+    phi = k / nsample
+    u = np.sqrt(2.0) * erfinv(phi)
+    sig = thr / u
+    g = np.sqrt(2.0 / np.pi) * u * np.exp(-0.5 * u * u)
+    tab[kmin:kmax + 1, 0] = (sig * np.sqrt(1.0 - g / phi)).astype(np.float32)
+    tab[kmin:kmax + 1, 1] = (sig * np.sqrt(1.0 + g / (1.0 - phi))).astype(np.float32)
+    return tab
+
+
+def unpack_2bit_dynamic(payload: np.ndarray, nsample: int = DLS_NSAMPLE, cutoff_sigma: float = DLS_CUTOFF_SIGMA,
+                        threshold: float = DLS_THRESHOLD) -> np.ndarray:
+    """u8[nbytes] -> f64[2][2*nbytes] with the levels of each window looked up by its low-state count (see above).
+    The sample count must be a multiple of the window (the filterbank's blocks are)."""
+    b = payload.astype(np.uint8)
+    st = np.empty((2, b.size * 2), dtype=np.uint8)          # offset-binary states, same bit layout as unpack_2bit
+    st[0, 0::2] = b & 3
+    st[1, 0::2] = (b >> 2) & 3
+    st[0, 1::2] = (b >> 4) & 3
+    st[1, 1::2] = (b >> 6) & 3
+    assert st.shape[1] % nsample == 0, "sample count must be a multiple of the window"
+    low = (st == 1) | (st == 2)
+    k = low.reshape(2, -1, nsample).sum(axis=2)             # [pol][window]
+    tab = dls_table(nsample, cutoff_sigma, threshold).astype(np.float64)
+    lev = tab[k]                                            # [pol][window][2]
+    mag = np.where(low.reshape(2, -1, nsample), lev[:, :, 0:1], lev[:, :, 1:2]).reshape(2, -1)
+    return np.where(st >= 2, mag, -mag)
+
+
 LEVELS_1BIT = np.array([-1.0, 1.0], dtype=np.float64)
 
 
@@ -196,7 +257,11 @@ def unpack_1bit(payload: np.ndarray) -> np.ndarray:
     return out
 
 
-def unpack(payload: np.ndarray, bits: int, levels=None) -> np.ndarray:
+def unpack(payload: np.ndarray, bits: int, levels=None, dynamic=None) -> np.ndarray:
+    """dynamic: None = static table; dict(nsample=, cutoff_sigma=, threshold=) = dynamic level setting (2 bit only)"""
+    if dynamic is not None:
+        assert bits == 2, "dynamic level setting needs 2-bit input"
+        return unpack_2bit_dynamic(payload, **dynamic)
     return unpack_1bit(payload) if bits == 1 else unpack_2bit(payload, levels)
 
 
@@ -485,6 +550,7 @@ class Config:
     dec: str = "00:00:00.0"
     rawdatafile: str = ""
     levels: tuple | None = None     # 2-bit level table (None = DSPSR's static one)
+    dynamic: dict | None = None     # dynamic level setting instead: dict(nsample=, cutoff_sigma=, threshold=) (unpack_2bit_dynamic)
     fixed_offset: np.ndarray | None = None   # set_rescale equivalent
     fixed_scale: np.ndarray | None = None
     result: dict = field(default_factory=dict)
@@ -518,7 +584,7 @@ def detected_power(raw_frames: np.ndarray, cfg: Config):
     nblocks = (nsamp - n) // hop + 1 if nsamp >= n else 0
     b_lo = s0 // spb
     b_hi = b_lo + ((nblocks - 1) * hop + n) // spb if nblocks else b_lo
-    x = unpack(payload[b_lo:b_hi], bits, cfg.levels)
+    x = unpack(payload[b_lo:b_hi], bits, cfg.levels, cfg.dynamic)
     if bad_frames.any() and b_hi > b_lo:              # invalid / filler frames: zero voltages
         pbytes = hdr.payload_bytes
         byte_bad = np.repeat(bad_frames, pbytes)[b_lo:b_hi]

@@ -41,16 +41,22 @@ def make_case(bw, nchan, secs, **kw):
 
 
 def oracle_cfg(bw, nchan, secs, pol=2, nbit=8, tscr=1, interval=10.0, const=1, freq_res=0, start=0.0,
-               dm=0.0, coherent=0, freq=1608.0, levels=None):
+               dm=0.0, coherent=0, freq=1608.0, levels=None, dynamic=None):
+    if dynamic is not None:   # dynamic level setting: dict of nsample / cutoff_sigma / threshold (missing = the defaults)
+        dynamic = dict(nsample=dynamic.get("nsample", o.DLS_NSAMPLE), cutoff_sigma=dynamic.get("cutoff_sigma", o.DLS_CUTOFF_SIGMA),
+                       threshold=dynamic.get("threshold", o.DLS_THRESHOLD))
     return o.Config(bw_mhz=bw, nchan=nchan, total_s=secs, start_s=start, pol_mode=pol, nbit=nbit,
                     tscrunch=tscr, rescale_interval_s=interval, rescale_constant=bool(const),
                     freq_res=freq_res, source="unknown", telescope="ONSALA85", dm=dm, coherent=bool(coherent),
-                    freq_mhz=freq, levels=levels)
+                    freq_mhz=freq, levels=levels, dynamic=dynamic)
 
 
 def lib_cfg(lib, bw, nchan, secs, pol=2, nbit=8, tscr=1, interval=10.0, const=1, freq_res=0, start=0.0, maxb=0, flags=0,
-            dm=0.0, coherent=0, freq=1608.0, levels=None):
+            dm=0.0, coherent=0, freq=1608.0, levels=None, dynamic=None):
     kw = {} if levels is None else {"levels": levels}
+    if dynamic is not None:
+        kw.update(unpack_mode=1, dls_nsample=dynamic.get("nsample", 0), dls_cutoff_sigma=dynamic.get("cutoff_sigma", 0.0),
+                  dls_threshold=dynamic.get("threshold", 0.0))
     return ch.new_config(lib, bw_mhz=bw, nchan=nchan, total_s=secs, start_s=start, pol_mode=pol,
                          nbit_out=nbit, tscrunch=tscr, rescale_interval_s=interval,
                          rescale_constant=const, freq_res=freq_res, max_blocks_per_launch=maxb, flags=flags,
@@ -121,7 +127,7 @@ def run_streaming_case(lib, bw, nchan, secs, **kw):
     okw = {k: v for k, v in kw.items() if k not in ("maxb", "flags")}
     # cases that differ only in kernel selection (flags) or batching (maxb) share ONE oracle run (the fp64 numpy chain at 2^24 .. 2^26
     # points is most of the GPU suite's wall time); the last few results are kept
-    key = (bw, nchan, secs, tuple(sorted((k, (tuple(v) if isinstance(v, (list, tuple)) else v)) for k, v in okw.items())), tuple(sorted(gen.items())))
+    key = (bw, nchan, secs, tuple(sorted((k, (tuple(v) if isinstance(v, (list, tuple)) else (tuple(sorted(v.items())) if isinstance(v, dict) else v))) for k, v in okw.items())), tuple(sorted(gen.items())))
     if key in _ORACLE_CACHE:
         ref, ocfg = _ORACLE_CACHE[key]
     else:

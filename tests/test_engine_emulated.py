@@ -35,6 +35,13 @@ CASES = [
     (16.0, 16, 0.012, dict(dm=1.0, coherent=1, freq=316.0, pol=3, nbit=2, tscr=8, interval=0.004, const=0)),
     (-16.0, 32, 0.012, dict(dm=0.7, coherent=1, freq=330.0, nbit=-32, start=0.001, bits=1)),
     (16.0, 64, 0.02, dict(dm=56.7, coherent=1, freq=1400.0, nbit=16, freq_res=128)),   # tiny smearing: 1 + 1 samples
+    # dynamic level setting (cfg.unpack_mode 1, the optional Jenet-Anderson unpack: DESIGN.md section 2a): windows of 512 and of 64
+    # samples, excision on (default 10 sigma), tight (2 sigma: many windows zeroed) and off, another threshold, frames of 1000 bytes
+    # (windows straddle frame boundaries), -S inside the file, four products, coherent
+    (16.0, 32, 0.03, dict(freq_res=64, dynamic={})),
+    (-16.0, 64, 0.03, dict(pol=4, dynamic=dict(nsample=64, cutoff_sigma=2.0))),
+    (16.0, 32, 0.03, dict(freq_res=64, nbit=-32, start=0.01, payload_bytes=1000, legacy=1, dynamic=dict(cutoff_sigma=-1.0, threshold=1.2))),
+    (16.0, 16, 0.012, dict(dm=1.0, coherent=1, freq=316.0, maxb=2, dynamic=dict(nsample=32))),
 ]
 
 

@@ -63,7 +63,7 @@ def test_unknown_flag_bits_are_rejected(emu_lib):
 
 def test_product_library_is_not_an_experiments_build(hip_lib):
     assert b"experiments" not in hip_lib.frbch_version()
-    assert b"abi 4" in hip_lib.frbch_version()
+    assert b"abi 5" in hip_lib.frbch_version()
 
 
 @pytest.mark.parametrize("bw,nchan,secs,kw", [
