@@ -100,8 +100,9 @@ def _tap(lib, payload, dynamic, on_device):
             d_raw = DeviceBuffer.from_numpy(raw)
             d_v = DeviceBuffer(2 * nsamp * 4)
             c.unpack_device(d_raw.ptr.value, nfr, 8032, 32, 0, nsamp, 0, d_v.ptr.value, d_v.nbytes)
+            d_v4 = DeviceBuffer(4 * nsamp * 4)
             with pytest.raises(ch.InputError):     # the register kernels' decoders do not look levels up per window
-                c.unpack_device(d_raw.ptr.value, nfr, 8032, 32, 0, nsamp, 1, d_v.ptr.value, d_v.nbytes)
+                c.unpack_device(d_raw.ptr.value, nfr, 8032, 32, 0, nsamp, 1, d_v4.ptr.value, d_v4.nbytes)
             return d_v.to_numpy(np.float32).reshape(2, nsamp)
         volt = np.zeros((2, nsamp), np.float32)
         c.unpack_device(raw.ctypes.data, nfr, 8032, 32, 0, nsamp, 0, volt.ctypes.data, volt.nbytes)
