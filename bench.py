@@ -613,6 +613,12 @@ def host_inclusive(args, torch, dist, wl, rank, world):
                         th.join()
                     t_null = timed(to_null)
                     t_fifo = timed(to_fifo)
+                    by_ref = bool(c.get_info().diag & 2)      # the rows went into the pipe by reference (vmsplice of the pinned ring)
+                    os.environ["FRBCH_FIFO_COPY"] = "1"       # the same with plain write() calls
+                    try:
+                        t_fifo_copy = timed(to_fifo)
+                    finally:
+                        del os.environ["FRBCH_FIFO_COPY"]
                 out60 = samples60 // 2       # 8-bit Stokes I: one byte per two dual-pol samples
                 res["long_scan"] = {
                     "scan": f"60 s of one {spec60['bw']:g} MHz IF -> {spec60['nchan']}-ch Stokes I 8 bit (-c -I 10: first interval buffered, then streamed)",
@@ -620,7 +626,10 @@ def host_inclusive(args, torch, dist, wl, rank, world):
                     "dev_null": {"value": round(samples60 / t_null / 1e6, 1), "unit": "Msamples/s", "s_per_scan": round(t_null, 4),
                                  "pcie_frac_each_way": round(out60 / t_null / 1e9 / PCIE_PEAK_GBS, 4)},
                     "fifo_drained": {"value": round(samples60 / t_fifo / 1e6, 1), "unit": "Msamples/s", "s_per_scan": round(t_fifo, 4),
-                                     "pcie_frac_each_way": round(out60 / t_fifo / 1e9 / PCIE_PEAK_GBS, 4)}}
+                                     "pcie_frac_each_way": round(out60 / t_fifo / 1e9 / PCIE_PEAK_GBS, 4), "by_reference": by_ref,
+                                     "sink_GBs": round(out60 / t_fifo / 1e9, 2)},
+                    "fifo_drained_write_only": {"value": round(samples60 / t_fifo_copy / 1e6, 1), "unit": "Msamples/s",
+                                                "s_per_scan": round(t_fifo_copy, 4), "sink_GBs": round(out60 / t_fifo_copy / 1e9, 2)}}
             finally:
                 for f in (vd60, fifo):
                     try:

@@ -271,6 +271,57 @@ bool write_all(int fd, const uint8_t* p, size_t n) {
   }
   return true;
 }
+
+// A FIFO sink (base2fil.sh:348-350: digifil writes into a named pipe that sigproc `splice` read()s, enlarged to 1 MiB by
+// setfifo.perl:10).  write() copies every byte into pipe pages; vmsplice() hands the pages of the (pinned) slot to the pipe BY
+// REFERENCE -- measured alone, tools/micro/pipe_bench: 8.6 against 5.9 GB/s for a 16-MiB slot into a drained 1-MiB FIFO.  Pages given
+// by reference must stay untouched until the reader has taken them, so the LAST pipe's worth of every buffer is copied with write():
+// the pipe is a ring of pipe_size / page buffers, and when that write has returned the ring holds nothing but its copies -- every
+// page handed over before it has been consumed and the caller may refill the buffer at once (no deeper ring, no bookkeeping).
+// Falls back to write() for good when the first vmsplice is refused (not a pipe, pages that cannot be referenced), and with
+// FRBCH_FIFO_COPY=1 in the environment (for a reader that forwards the pages by reference itself instead of read()ing them).
+struct FifoSink {
+  size_t pipe_bytes = 0;     // 0 = not a FIFO
+  bool by_reference = false;
+  uint64_t referenced = 0;   // bytes that went out by reference (frbch_info::diag bit 1 says whether any did)
+};
+FifoSink probe_sink(int fd) {
+  FifoSink f;
+  struct stat st;
+  if (fd < 0 || fstat(fd, &st) != 0 || !S_ISFIFO(st.st_mode)) return f;
+#ifdef F_GETPIPE_SZ
+  const int sz = fcntl(fd, F_GETPIPE_SZ);
+  if (sz > 0) f.pipe_bytes = (size_t)sz;
+#endif
+  const char* e = getenv("FRBCH_FIFO_COPY");
+  f.by_reference = f.pipe_bytes >= 65536 && !(e && *e && *e != '0');
+  return f;
+}
+bool sink_write(int fd, const uint8_t* p, size_t n, FifoSink* f) {
+  if (f && f->by_reference && n > 2 * f->pipe_bytes) {
+    const size_t nv = (n - f->pipe_bytes) & ~(size_t)4095;
+    size_t left = nv;
+    while (left) {
+      struct iovec iov = {const_cast<uint8_t*>(p) + (nv - left), left};
+      const ssize_t w = vmsplice(fd, &iov, 1, 0);
+      if (w < 0) {
+        if (errno == EINTR) continue;
+        if (left == nv && (errno == EFAULT || errno == EINVAL || errno == EBADF || errno == ENOSYS || errno == EPERM || errno == ENOMEM)) {
+          f->by_reference = false;     // nothing of this buffer has gone out yet: copy it, and every later one
+          break;
+        }
+        return false;
+      }
+      left -= (size_t)w;
+      f->referenced += (uint64_t)w;
+    }
+    if (f->by_reference) {
+      p += nv;
+      n -= nv;
+    }
+  }
+  return write_all(fd, p, n);
+}
 }  // namespace
 
 namespace {
@@ -431,7 +482,7 @@ int run_pipelined(frbch_handle* const* hs, uint32_t nif, const int* in_fds, int 
       return fail(h0, FRBCH_E_NOMEM, "pinned staging buffers");
   auto release = [&]() {};   // (the rings stay with the handle until frbch_close)
   // (started only now: no early return is left between here and the join at the end of this function)
-  h0->diag &= ~1u;
+  h0->diag &= ~3u;
   if (out_expect)
     prealloc = std::thread([&]() {
 #ifdef FRBCH_TEST_HOOKS
@@ -465,6 +516,7 @@ int run_pipelined(frbch_handle* const* hs, uint32_t nif, const int* in_fds, int 
   }
 
   PipeQueue qin, qout;
+  FifoSink fsink = probe_sink(out_fd);              // (one writer when the output is not a preallocated regular file)
   std::vector<std::thread> readers, writers;
   for (int r = 0; r < NR; ++r)
     readers.emplace_back([&, r]() {                // reader r owns input slot r: pieces r, r + NR, ...
@@ -536,7 +588,7 @@ int run_pipelined(frbch_handle* const* hs, uint32_t nif, const int* in_fds, int 
             qout.cv.notify_all();
           }
         } else {
-          ok = write_all(out_fd, outbuf[slot], n);
+          ok = sink_write(out_fd, outbuf[slot], n, &fsink);
         }
         const int err = ok ? 0 : (errno ? errno : EIO);
         std::lock_guard<std::mutex> lk(qout.m);
@@ -708,6 +760,7 @@ int run_pipelined(frbch_handle* const* hs, uint32_t nif, const int* in_fds, int 
     if (!rc && qout.error) rc = fail(h0, FRBCH_E_IO, std::string("write: ") + strerror(qout.error));
   }
   if (prealloc.joinable()) prealloc.join();
+  if (fsink.referenced) h0->diag |= 2u;   // frbch_info::diag bit 1: a FIFO took pages of the pinned ring by reference (vmsplice)
   if (omap) {
     munmap(omap, (size_t)out_expect);
     h0->diag |= 1u;            // frbch_info::diag bit 0: the output went through the shared mapping
@@ -885,6 +938,7 @@ extern "C" int frbch_run_scan(frbch_handle* const* ifs, uint32_t nif, const char
   }
   if (!rc && dev_host_alloc((void**)&stage, stage_bytes) != 0) rc = fail(h0, FRBCH_E_NOMEM, "pinned staging buffer");
   bool header_done = false;
+  FifoSink fsink = probe_sink(fd);
   // write the rows every IF has delivered; rows only some IFs have stay in the buffer (moved to its top)
   auto drain = [&](bool final_) -> int {
     uint64_t n = UINT64_MAX, most = 0;
@@ -906,7 +960,7 @@ extern "C" int frbch_run_scan(frbch_handle* const* ifs, uint32_t nif, const char
       if (!nr) return fail(h0, FRBCH_E_CAPACITY, "row larger than the staging buffer");
       CHECK_DEV(h0, dev_d2h(stage, d_rows + r0 * row_pitch, nr * row_pitch, h0->stream), "download scan rows");
       CHECK_DEV(h0, dev_sync(h0->stream), "sync");
-      if (!write_all(fd, stage, nr * row_pitch)) return fail(h0, FRBCH_E_IO, std::string("write: ") + strerror(errno));
+      if (!sink_write(fd, stage, nr * row_pitch, &fsink)) return fail(h0, FRBCH_E_IO, std::string("write: ") + strerror(errno));
       r0 += nr;
     }
     if (final_) return FRBCH_OK;                      // cut to the shortest IF, as splice does

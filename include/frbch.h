@@ -119,7 +119,8 @@ typedef struct frbch_info {
   uint32_t frame_bytes, header_bytes;
   uint32_t have_rescale;       /* offset/scale are defined                                     */
   uint32_t diag;               /* diagnostics of the last call: bit 0 = the whole-file path wrote a regular output file through its
-                                  preallocated shared mapping (parallel copies) instead of write() calls                     */
+                                  preallocated shared mapping (parallel copies) instead of write() calls; bit 1 = a FIFO output
+                                  took the rows by reference (vmsplice of the pinned ring; FRBCH_FIFO_COPY=1 forces write())   */
   uint64_t frames_seen;        /* host streaming path: frames whose header was checked           */
   uint64_t frames_invalid;     /* ... with the VDIF invalid bit set: their samples enter the filterbank as 0 (the level table's
                                   mean), extract_baseband_chunk.py:56-69 reads the same bit                            */

@@ -186,6 +186,38 @@ def test_run_file_into_fifo(emu_lib, tmp_path):
             c.run_file(str(tmp_path / "missing.vdif"), out)
 
 
+def test_fifo_takes_large_outputs_by_reference(emu_lib, tmp_path, monkeypatch):
+    """a FIFO sink (base2fil.sh:348-350) with more than two pipes' worth per slot: the rows go out through vmsplice (frbch_info.diag
+    bit 1), the last pipe's worth of every slot by write(); same bytes as the regular-file output, and as with FRBCH_FIFO_COPY=1"""
+    raw = synth.make_vdif(0.04, bw_mhz=16.0, nchan=32)
+    vd = tmp_path / "a_IF1.vdif"
+    raw.tofile(vd)
+    kw = dict(freq_res=64, pol=4, nbit=-32)          # 512-byte rows: ~10 MB of output
+    out = str(tmp_path / "o.fil")
+    with ch.Channeliser(pu.lib_cfg(emu_lib, 16.0, 32, 0.04, **kw), emu_lib) as c:
+        c.run_file(str(vd), out)
+    want = open(out, "rb").read()
+    assert len(want) > 4 << 20
+    for copy in (False, True):
+        if copy:
+            monkeypatch.setenv("FRBCH_FIFO_COPY", "1")
+        fifo = str(tmp_path / f"f{int(copy)}.fil")
+        os.mkfifo(fifo)
+        got = {}
+
+        def reader():
+            with open(fifo, "rb") as f:
+                got["data"] = f.read()
+        th = threading.Thread(target=reader)
+        th.start()
+        with ch.Channeliser(pu.lib_cfg(emu_lib, 16.0, 32, 0.04, **kw), emu_lib) as c:
+            c.run_file(str(vd), fifo)
+            diag = c.get_info().diag
+        th.join(timeout=60)
+        assert got["data"] == want
+        assert bool(diag & 2) == (not copy)
+
+
 def test_device_entry_points_and_power_tap(emu_lib):
     """frbch_process_device / flush_device / power_device semantics (emulator: host pointers)."""
     bw, nchan, r = 16.0, 32, 64
