@@ -144,6 +144,38 @@ def test_digifil_shim_into_fifo(tmp_path):
         pv.run_digifil(str(tmp_path / "missing.hdr"), str(tmp_path), 0, 1, 1024, overwrite=True, backend="shim")
 
 
+def test_fifo_sink_takes_the_pinned_ring_by_reference(hip_lib, tmp_path, monkeypatch):
+    """base2fil.sh:348-350: the sink of a scan is a named pipe.  Outputs of more than two pipes' worth per slot go out through
+    vmsplice of the hipHostMalloc'ed ring (frbch_info.diag bit 1) -- same bytes as a regular file and as with FRBCH_FIFO_COPY=1"""
+    raw = synth.make_vdif(1.0, bw_mhz=32.0, nchan=1024)
+    vd = str(tmp_path / "a_IF1.vdif")
+    raw.tofile(vd)
+    kw = dict(pol=5, interval=0.3)                     # 4096-byte rows, 31 k rows: 128 MB
+    out = str(tmp_path / "o.fil")
+    with ch.Channeliser(pu.lib_cfg(hip_lib, 32.0, 1024, 1.0, **kw), hip_lib) as c:
+        c.run_file(vd, out)
+    want = open(out, "rb").read()
+    assert len(want) > 64 << 20
+    for copy in (False, True):
+        if copy:
+            monkeypatch.setenv("FRBCH_FIFO_COPY", "1")
+        fifo = str(tmp_path / f"f{int(copy)}.fil")
+        os.mkfifo(fifo)
+        got = {}
+
+        def reader():
+            with open(fifo, "rb") as f:
+                got["data"] = f.read()
+        th = threading.Thread(target=reader)
+        th.start()
+        with ch.Channeliser(pu.lib_cfg(hip_lib, 32.0, 1024, 1.0, **kw), hip_lib) as c:
+            c.run_file(vd, fifo)
+            diag = c.get_info().diag
+        th.join(timeout=120)
+        assert got["data"] == want
+        assert bool(diag & 2) == (not copy)
+
+
 def test_known_pulsar_flags_through_the_harness(tmp_path):
     """process_vdif.py:177-180: `-D <dm> -F<C>:D` appended after `-F<C>:<R>` (last wins) -> coherent filterbank,
     in-process through the C-ABI; refdm lands in the SIGPROC header."""

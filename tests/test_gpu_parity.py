@@ -88,6 +88,10 @@ CASES = [
     (16.0, 128, 0.05, dict(pol=5, tscr=8, nbit=-32)),        # 2C = 256 wave K2
     (64.0, 4096, 0.55, dict(pol=5, tscr=2)),                  # M = 32
     (-32.0, 512, 0.15, dict(dm=26.7, coherent=1, freq=350.0, pol=5, tscr=2)),   # K3 (register passes)
+    # the online chain's upper limit, 2^13 channels (submit_job.py:42,61-71): 2C = 16384 runs the generic radix-2 K2 (one sequence fills
+    # the LDS); K1 is the wave kernel up to freq_res 8192 and generic at the default freq_res = 2 C = 16384 (DESIGN.md sections 8.1, 9)
+    (64.0, 8192, 0.15, dict(freq_res=512)),                   # wave K1 (M = 2) + generic K2, 2 blocks of 2^23 samples
+    (-64.0, 8192, 0.15, dict(freq_res=1024, pol=4, nbit=16)),   # (four products AND -t > 1 at 8192 channels: InputError, the generic K2's accumulators do not fit the LDS)
     # few channels per IF (the online chain's 32 / 64, submit_job.py:74-105; R = 512 as process_vdif.py:162 says): wave K1 (M = 2) +
     # frbch_k2_lane (a whole 64-point across-branch sequence per lane; 2C = 128: per lane pair)
     (16.0, 32, 0.02, {}),
