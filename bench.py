@@ -341,13 +341,18 @@ class Workload:
         nif = spec["nif"]
         self.cfg_kwargs = []
         self.chans = []
+        world = int(os.environ.get("WORLD_SIZE", "1") or 1)
         for i in range(nif):
             # IF numbering and sidebands as base2fil.sh:30-67 (odd IFs LSB, even USB); rows in splice order: highest IF first
             ifno = nif - i
+            # sky frequencies: the IFs of the node tile one band around spec["freq"], descending in splice order, rank 0 on top
+            # (base2fil.sh:54,65,254) -- frbch_join checks that the ranks' pieces continue each other in frequency
+            g = rank * nif + i
+            freq = spec["freq"] if spec["coherent"] else spec["freq"] + ((world * nif - 1) / 2.0 - g) * spec["bw"]
             kw = dict(bw_mhz=-spec["bw"] if ifno % 2 else spec["bw"], nchan=spec["nchan"], pol_mode=spec["pol"], nbit_out=8,
                       tscrunch=spec["tscrunch"], rescale_constant=1, rescale_interval_s=10.0, total_s=spec["seconds"] * spec.get("tile", 1),
                       device=local_rank, max_blocks_per_launch=args.maxb, flags=args.flags, dm=spec["dm"],
-                      coherent=1 if spec["coherent"] else 0, freq_mhz=spec["freq"], freq_res=spec["freq_res"], overlap=args.overlap)
+                      coherent=1 if spec["coherent"] else 0, freq_mhz=freq, freq_res=spec["freq_res"], overlap=args.overlap)
             if nif == 1:
                 kw["bw_mhz"] = spec["bw"]
             self.cfg_kwargs.append(kw)
@@ -644,7 +649,11 @@ def host_inclusive(args, torch, dist, wl, rank, world):
             from frb_baseband_amd import multi_if, scan as scan_mod
             tag = os.environ.get("MASTER_PORT", "0")
             fifos = [os.path.join(base, f"frbch_bench_join_{tag}_rank{r}.fil") for r in range(world)]
-            chans = [ch.Channeliser(ch.new_config(**kw)) for kw in wl.cfg_kwargs[:nif]]
+            # (the `nif` IFs of this leg tile one band across the ranks, rank 0 on top: frbch_join checks the pieces' continuity)
+            bw_leg = abs(wl.cfg_kwargs[0]["bw_mhz"])
+            chans = [ch.Channeliser(ch.new_config(**(kw if wl.spec["coherent"] else
+                                                    dict(kw, freq_mhz=wl.spec["freq"] + ((world * nif - 1) / 2.0 - (rank * nif + i)) * bw_leg))))
+                     for i, kw in enumerate(wl.cfg_kwargs[:nif])]
             try:
                 def node_scan():
                     join = None
