@@ -280,7 +280,9 @@ def collect_traffic(argv):
             # own process group: on a timeout the profiler AND the python it started (which holds the GPU) are killed
             pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
             try:
-                rc = pr.wait(timeout=420)   # (the first `import torch` on a fresh box alone can take 1 - 2 minutes)
+                # (the first `import torch` on a fresh box alone can take 1 - 2 minutes; a pass takes 15 - 30 s after that.  On one box
+                # of the pool the FETCH_SIZE pass hung behind the HSA initialisation -- the limit is what such a box costs the bench)
+                rc = pr.wait(timeout=300 if cnt == "FETCH_SIZE" else 180)
             except subprocess.TimeoutExpired:
                 import signal
                 try:

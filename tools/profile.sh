@@ -10,9 +10,9 @@ echo "bench done rc=$?"
 plain="--no-cpu --no-host --no-traffic --no-configs --no-steady"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py $plain > $out/trace_bench.json 2> $out/trace.err
 echo "trace done rc=$?"
-timeout -k 10 420 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py $plain --steps 1 --warmup 1 > $out/fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py $plain --steps 1 --warmup 1 > $out/fetch.log 2>&1
 echo "fetch done rc=$?"
-timeout -k 10 420 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py $plain --steps 1 --warmup 1 > $out/write.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py $plain --steps 1 --warmup 1 > $out/write.log 2>&1
 echo "write done rc=$?"
 python3 - <<PY
 import csv, glob, collections, json
