@@ -530,7 +530,13 @@ bool launch_k2c_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   const Plan& pl = h->pl;
   if (!pl.coh_fast_c) return false;
   const int tt = 1024 / (16 << pl.coh_fast_c);
-  const dim3 grid(pl.r / tt, nb);
+  // a workgroup keeps its positions (and their kernel factors, in registers) and walks the blocks of the launch; enough workgroups
+  // for a few rounds per CU, else the block index strides too
+  p.nblk = nb;
+  const uint32_t ntile = (uint32_t)(pl.r / tt);
+  const uint32_t want = 4u * (uint32_t)std::max(1, h->lane_ncu);
+  const uint32_t gy = std::max<uint32_t>(1, std::min<uint32_t>(nb, (want + ntile - 1) / ntile));
+  const dim3 grid(ntile, gy);
   switch (pl.coh_fast_c) {
     case 1: hipLaunchKernelGGL((fast::frbch_k2c_fast<1, 1024>), grid, dim3(1024), pl.k2c_fast_lds, s, p); break;
     case 2: hipLaunchKernelGGL((fast::frbch_k2c_fast<2, 1024>), grid, dim3(1024), pl.k2c_fast_lds, s, p); break;
