@@ -906,7 +906,7 @@ int launch_back(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
   }
   if (pl.coherent) {   // K2c (branches -> channels, x kernel), K3 (back to time, detect), K4 (time-major rows)
     {
-      ProfScope ps(h, s, KID_K2, (double)nb * (double)pl.n * 24.0);
+      ProfScope ps(h, s, KID_K2, ((double)nb * 16.0 + (pl.coh_fast_c ? 1.0 : (double)nb) * 8.0) * (double)pl.n);   // the register K2c reads the kernel table once per launch
       if (!launch_k2c_fast(h, p, nb, s)) DEV_LAUNCH(frbch_k2c_chirp, pl.r / pl.tt, nb, pl.nthreads, pl.k2_lds, s, p);
     }
     {
