@@ -139,10 +139,10 @@ void launch_k1_wave_t(const Plan& pl, KParams& p, uint32_t nb, dev_stream_t s, i
 #endif
     if (want <= nb) ny = want;
   }
-  const size_t lds_msk = pl.k1_fast_lds + (size_t)pl.r;   // + one flag byte per n2 row (frames flagged invalid / fillers: MSK)
+  const size_t lds_msk = pl.k1_fast_lds + (size_t)(LOG2M >= 5 ? pl.r / 8 : pl.r);   // + one flag per n2 row (frames flagged invalid / fillers: MSK): a byte, at R = 8192 a bit
 #define FRBCH_K1W(L, NWV, WPSV, NTV)                                                                                       \
   do {                                                                                                                  \
-    if (p.stg && p.fbad) hipLaunchKernelGGL((fast::frbch_k1_wave<L, NWV, WPSV, true, false, (L < 5)>), dim3(ngrp, ny), dim3(NTV), lds_msk, s, p);  \
+    if (p.stg && p.fbad) hipLaunchKernelGGL((fast::frbch_k1_wave<L, NWV, WPSV, true, false, true>), dim3(ngrp, ny), dim3(NTV), lds_msk, s, p);  \
     else if (p.stg) hipLaunchKernelGGL((fast::frbch_k1_wave<L, NWV, WPSV, true>), dim3(ngrp, ny), dim3(NTV), pl.k1_fast_lds, s, p);  \
     else hipLaunchKernelGGL((fast::frbch_k1_wave<L, NWV, WPSV, false>), dim3(ngrp, ny), dim3(NTV), pl.k1_fast_lds, s, p);        \
   } while (0)
@@ -376,9 +376,9 @@ bool launch_k1_fast(frbch_handle* h, KParams& p, uint32_t nb, dev_stream_t s) {
     set_fastdiv(q);
     if (h->stg_ready) q.stg = h->stg_cur ? h->stg_cur : h->stg;   // launch_k0_stage has corner-turned this batch
     h->stg_ready = false;
-    if (p.fbad) {   // flagged frames: only the staged wave K1 below R = 8192 masks them (a flag byte per row beside the stage)
-      if (!q.stg || pl.fast_k1_log2m >= 5 || pl.fast_k1_kind == 1 || pl.fast_k1_kind == 2 || pl.fast_k1_kind == 3 || pl.fast_k1_split ||
-          pl.k1_fast_lds + (size_t)pl.r > h->lds_limit)
+    if (p.fbad) {   // flagged frames: the staged wave K1 masks them (a flag per row beside the stage: a byte, at R = 8192 a bit)
+      if (!q.stg || pl.fast_k1_kind == 1 || pl.fast_k1_kind == 2 || pl.fast_k1_kind == 3 || pl.fast_k1_split ||
+          pl.k1_fast_lds + (size_t)(pl.fast_k1_log2m >= 5 ? pl.r / 8 : pl.r) > h->lds_limit)
         return false;
       q.fbad_frame0 = p.fbad_frame0 + fr0;
     }
@@ -639,8 +639,8 @@ int setup_fast(frbch_handle* h) {
       CHECK_DEV(h, dev_malloc((void**)&h->stg, (size_t)pl.maxb * pl.block_payload_bytes), "hipMalloc(staged payload)");
 #define FRBCH_AL(L, NWV, WPSV) do { if (!rc) rc = allow_lds(h, fast::frbch_k1_wave<L, NWV, WPSV, false>, pl.k1_fast_lds); \
                                     if (!rc) rc = allow_lds(h, fast::frbch_k1_wave<L, NWV, WPSV, true>, pl.k1_fast_lds); \
-                                    if (!rc && L < 5 && pl.k1_fast_lds + (size_t)pl.r <= h->lds_limit) \
-                                      rc = allow_lds(h, fast::frbch_k1_wave<L, NWV, WPSV, true, false, (L < 5)>, pl.k1_fast_lds + (size_t)pl.r); } while (0)
+                                    if (!rc && pl.k1_fast_lds + (size_t)(L >= 5 ? pl.r / 8 : pl.r) <= h->lds_limit) \
+                                      rc = allow_lds(h, fast::frbch_k1_wave<L, NWV, WPSV, true, false, true>, pl.k1_fast_lds + (size_t)(L >= 5 ? pl.r / 8 : pl.r)); } while (0)
     rc = FRBCH_OK;
     if (pl.fast_k1_wave) switch (pl.fast_k1_log2m) {
       case 1: FRBCH_AL(1, 8, 1); break;

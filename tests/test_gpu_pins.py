@@ -417,9 +417,8 @@ def test_dropped_and_invalid_frames(hip_lib, tmp_path, pol, via_file):
 
 
 def test_invalid_frame_at_4096_channels(hip_lib):
-    """config-4 kernels, 2 blocks of 2^26 samples: block 0 is clean (wave K1 writes chunks of eight time samples, the wave
-    K2 reads 32-byte pieces of them), block 1 holds an invalid frame (generic K1 with the frame mask writes the slab
-    layout, the same wave K2 follows it)"""
+    """config-4 kernels, 2 blocks of 2^26 samples: block 0 is clean, block 1 holds an invalid frame -- since round 4 the SAME wave
+    K1 runs it in its masked form (R = 8192: one flag BIT per n2 row beside the staged payload; round 3: the generic K1)"""
     raw = synth.make_vdif(1.1, bw_mhz=64.0, nchan=4096)
     nfr = raw.size // 8032
     fr = raw.reshape(nfr, 8032).copy()
@@ -429,8 +428,11 @@ def test_invalid_frame_at_4096_channels(hip_lib):
     ref = o.channelise(inv, ocfg)
     assert ocfg.result["frame_counters"]["invalid"] == 1
     with ch.Channeliser(pu.lib_cfg(hip_lib, 64.0, 4096, 1.1), hip_lib) as c:
+        c.set_profiling(True)
         got = c.channelise_bytes(inv)
         assert c.get_info().frames_invalid == 1
+        names = {k for k, v in c.get_timing().items() if v["launches"]}
+    assert "frbch_k1_wave<5,8,4>" in names and not any("frbch_k1_branch" in n for n in names), names
     pu.check_codes(ref, got, ocfg)
 
 
