@@ -189,15 +189,15 @@ bool k3_wave_planned(const Plan& pl, uint32_t h_flags) {
 }
 // frbch_k2_priv: one row of partial sums per (workgroup, row phase); `grid` = its workgroups (one per CU)
 int priv_stat_chunks(const Plan& pl, int grid) { return grid * (pl.ncol / 4 >= 256 ? 1 : (int)(256 / (pl.ncol / 4))); }
-// which K2 a launch of a plan with frbch_k2_priv takes: float rows of four products stay on frbch_k2_wave (measured, config 3:
-// 1.87 ms per IF against 1.97 -- the phase is HBM-bound and the two-wave kernel reads whole 128-byte lines, frbch_k2_priv halves of
-// them twice), everything else -- codes, one product, statistics only -- runs frbch_k2_priv (steady state of config 3 + 2.4 %,
-// config 2 + 4 %)
+// which K2 a launch of a plan with frbch_k2_priv takes: float rows stay on frbch_k2_wave (measured: four products, config 3, 1.87 ms
+// per IF against 1.97; one product, config 2, 1.15 - 1.20 against 1.20 - 1.28 -- the two-wave kernel reads whole 128-byte lines,
+// frbch_k2_priv halves of them twice, and writing float rows leaves less of the memory pipe to hide that), codes and statistics-only
+// passes run frbch_k2_priv (steady state of config 3 + 2.4 %, config 2 + 4 %)
 bool pol_mode_no_sums(int pol_mode) { return pol_mode == 3; }   // (PP+QQ)^2: its square overflows the fp32 partial sums (~1e24 squared)
 bool priv_takes(const Plan& pl, const KParams& p, int priv_grid) {
   // (the two-wave kernel reads the tile-major spill only in its two-sample form: fast_k2_nw == 2, tscrunch <= 2)
   return pl.fast_k2_priv && p.tile_major == 2 && priv_grid > 0 &&
-         !(p.out_mode == FRBCH_OUT_FLOAT_POWER && pl.nif == 4 && pl.fast_k2_nw == 2 && pl.fast_k2_log2m == 3);
+         !(p.out_mode == FRBCH_OUT_FLOAT_POWER && pl.fast_k2_nw == 2 && pl.fast_k2_log2m == 3);
 }
 int wave_stat_chunks(const Plan& pl, uint32_t h_flags, int pol_mode);
 // rows of the table of partial rescale sums the kernels of this plan may write (both K2 families add into the same table: whatever
