@@ -124,6 +124,26 @@ def test_unpack_tap_equals_the_restatement_on_the_emulator(emu_lib, dynamic):
     assert np.array_equal(got, want)
 
 
+def test_invalid_and_missing_frames_with_dynamic_levels(emu_lib):
+    """the windows are counted on the payload as it lies in the stream handed to the filterbank (fillers are zero bytes: all samples
+    in the outer negative state, so a window inside a filler is zeroed by the excision anyway); samples of flagged frames are zeroed
+    AFTER the level lookup, as with the static table (DESIGN.md sections 2a, 3a)"""
+    from frb_baseband_amd import synth
+    raw = synth.make_vdif(0.012, bw_mhz=16.0, nchan=32).copy()
+    marked = raw.copy()
+    marked[3 * 8032 + 3] |= 0x80                                          # invalid bit of frame 3
+    marked = np.concatenate([marked[: 7 * 8032], marked[9 * 8032:]])     # frames 7 and 8 are missing
+    kw = dict(freq_res=64, dynamic=dict(nsample=128, cutoff_sigma=4.0))
+    ocfg = pu.oracle_cfg(16.0, 32, 0.012, **kw)
+    ref = o.channelise(marked, ocfg)
+    assert ocfg.result["frame_counters"] == dict(gaps=1, filled=2, invalid=1)
+    with ch.Channeliser(pu.lib_cfg(emu_lib, 16.0, 32, 0.012, **kw), emu_lib) as c:
+        got = c.channelise_bytes(marked)
+        info = c.get_info()
+    assert (info.frames_invalid, info.frame_gaps, info.frames_filled) == (1, 1, 2)
+    pu.check_codes(ref, got, ocfg)
+
+
 def test_configuration_errors(emu_lib):
     for kw in (dict(unpack_mode=2), dict(unpack_mode=1, dls_nsample=100), dict(unpack_mode=1, dls_nsample=8),
                dict(unpack_mode=1, input_bits=1), dict(unpack_mode=1, dls_threshold=-1.0),
