@@ -1021,7 +1021,7 @@ bool quant_fast_geometry(const frbch_handle* h, int ncu, int wgs_per_cu, uint64_
   if ((h->cfg.flags & kFlagGenericQuant) || h->cfg.nbit_out != 8 || pl.digi_max != 255.0f) return false;
   const uint64_t cg = pl.ncol / 4;
   const bool pow2 = (pl.ncol & (pl.ncol - 1)) == 0 && (pl.c & (pl.c - 1)) == 0;
-  if (!pow2 || pl.c < 4 || cg < 64) return false;
+  if (!pow2 || pl.c < 4 || cg < 8) return false;   // (narrow rows, 32 .. 128 columns: a wave covers several rows -- one contiguous run all the same)
   const bool excl = ncu < 0;
   const uint64_t nthr = excl ? 512 : 256;
   uint64_t rp = excl ? (uint64_t)(-ncu) * nthr / cg : (uint64_t)(ncu > 0 ? ncu : 256) * (uint64_t)(wgs_per_cu > 0 ? wgs_per_cu : 3) * 256 / cg;
